@@ -1,0 +1,1132 @@
+// CPU oracle: a C++17 restatement of the ShadowCurse/raytracing renderer.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+// product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+// leg may build, load or call it, and only as the checker / CPU baseline.
+//
+// PARITY UNPINNED: the reference ships no golden vectors, known-answer tests
+// or fixtures for this path (its only tests cover blobvec.rs byte layout) and
+// its Rust toolchain is absent here, so this restatement is anchored on the
+// reference sources alone (file:line cited at each function) plus
+// hand-derivable known answers checked in tests/.
+//
+// All arithmetic is IEEE f32, evaluated in the operator order of the Rust
+// source; build with -ffp-contract=off and without fast-math.
+//
+// Random numbers: the reference draws from rand::thread_rng() (OS seeded, not
+// reproducible).  Here every draw site pulls from a thread-local counter-based
+// Philox4x32-10 stream keyed on (pixel, sample, bounce, stage) so a render is
+// a pure function of (scene, camera, seed).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <typeindex>
+#include <typeinfo>
+#include <utility>
+#include <vector>
+
+namespace oracle {
+
+constexpr float PI_F = 3.14159265358979323846264338327950288f;
+constexpr float INF_F = std::numeric_limits<float>::infinity();
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Known answers are checked in tests/.
+// ---------------------------------------------------------------------------
+struct Philox {
+  static inline void round(uint32_t c[4], const uint32_t k[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  static inline void block(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    uint32_t k[2] = {key[0], key[1]};
+    for (int i = 0; i < 10; ++i) {
+      round(c, k);
+      k[0] += 0x9E3779B9u;
+      k[1] += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+  }
+};
+
+// Stage ids inside one bounce.  Draws inside a stage are consumed
+// sequentially, except STAGE_MEDIA where medium number m always reads draw m.
+enum : uint32_t { STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SHADE = 2 };
+
+struct Sampler {
+  uint32_t key[2] = {0, 0};
+  uint32_t pixel = 0, sample = 0, bounce = 0, stage = 0;
+  uint32_t next_index = 0;
+  uint32_t cached_block = 0xFFFFFFFFu;
+  uint32_t cache[4];
+
+  void begin(uint32_t bounce_, uint32_t stage_) {
+    bounce = bounce_; stage = stage_; next_index = 0; cached_block = 0xFFFFFFFFu;
+  }
+  float at(uint32_t index) {
+    const uint32_t blk = index >> 2;
+    if (blk != cached_block) {
+      const uint32_t ctr[4] = {pixel, sample, bounce * 4u + stage, blk};
+      Philox::block(ctr, key, cache);
+      cached_block = blk;
+    }
+    return (float)(cache[index & 3u] >> 8) * (1.0f / 16777216.0f);  // [0,1), 24 bits
+  }
+  float next() { return at(next_index++); }
+};
+
+inline Sampler*& tls_sampler() {
+  thread_local Sampler* s = nullptr;
+  return s;
+}
+inline float rand01() { return tls_sampler()->next(); }
+inline float rand_range(float lo, float hi) { return lo + (hi - lo) * rand01(); }
+
+// ---------------------------------------------------------------------------
+// vec3.rs
+// ---------------------------------------------------------------------------
+struct Vec3 {
+  float x = 0.0f, y = 0.0f, z = 0.0f;
+  Vec3() = default;
+  Vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
+
+  float length_squared() const { return x * x + y * y + z * z; }  // vec3.rs:94-96
+  float length() const { return std::sqrt(length_squared()); }    // vec3.rs:90-92
+  float dot(const Vec3& r) const { return x * r.x + y * r.y + z * r.z; }  // vec3.rs:119-121
+  Vec3 cross(const Vec3& r) const {  // vec3.rs:123-129
+    return Vec3(y * r.z - z * r.y, z * r.x - x * r.z, x * r.y - y * r.x);
+  }
+  Vec3 unit() const {  // vec3.rs:103-106 (true division per component)
+    const float len = length();
+    return Vec3(x / len, y / len, z / len);
+  }
+};
+using Point3 = Vec3;
+using Color = Vec3;
+
+inline Vec3 operator-(const Vec3& a) { return Vec3(-a.x, -a.y, -a.z); }
+inline Vec3 operator+(const Vec3& a, const Vec3& b) { return Vec3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline Vec3 operator-(const Vec3& a, const Vec3& b) { return Vec3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline Vec3 operator*(float s, const Vec3& v) { return Vec3(v.x * s, v.y * s, v.z * s); }
+inline Vec3 operator*(const Vec3& v, float s) { return Vec3(v.x * s, v.y * s, v.z * s); }
+inline Vec3 operator*(const Vec3& a, const Vec3& b) { return Vec3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline Vec3 operator/(const Vec3& v, float s) { return Vec3(v.x / s, v.y / s, v.z / s); }
+inline Vec3& operator+=(Vec3& a, const Vec3& b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+
+inline Vec3 vec3_random(float lo, float hi) {  // vec3.rs:20-28
+  const float x = rand_range(lo, hi);
+  const float y = rand_range(lo, hi);
+  const float z = rand_range(lo, hi);
+  return Vec3(x, y, z);
+}
+inline Vec3 random_in_unit_sphere() {  // vec3.rs:44-51
+  for (;;) {
+    const Vec3 p = vec3_random(-1.0f, 1.0f);
+    if (p.length_squared() < 1.0f) return p;
+  }
+}
+inline Vec3 random_in_unit_disk() {  // vec3.rs:53-60 (random_vec2: z = 0)
+  for (;;) {
+    const float x = rand_range(-1.0f, 1.0f);
+    const float y = rand_range(-1.0f, 1.0f);
+    const Vec3 p(x, y, 0.0f);
+    if (p.length_squared() < 1.0f) return p;
+  }
+}
+inline Vec3 random_cosine_direction() {  // vec3.rs:62-74
+  const float r1 = rand01();
+  const float r2 = rand01();
+  const float z = std::sqrt(1.0f - r2);
+  const float phi = 2.0f * PI_F * r1;
+  const float x = std::cos(phi) * std::sqrt(r2);
+  const float y = std::sin(phi) * std::sqrt(r2);
+  return Vec3(x, y, z);
+}
+inline Vec3 random_to_sphere(float radius, float distance_squared) {  // vec3.rs:76-88
+  const float r1 = rand01();
+  const float r2 = rand01();
+  const float z = 1.0f + r2 * (std::sqrt(1.0f - radius * radius / distance_squared) - 1.0f);
+  const float phi = 2.0f * PI_F * r1;
+  const float x = std::cos(phi) * std::sqrt(1.0f - z * z);
+  const float y = std::sin(phi) * std::sqrt(1.0f - z * z);
+  return Vec3(x, y, z);
+}
+inline Vec3 reflect(const Vec3& v, const Vec3& n) {  // vec3.rs:108-110
+  return v - (2.0f * v.dot(n)) * n;
+}
+inline Vec3 refract(const Vec3& v, const Vec3& n, float etai_over_etat) {  // vec3.rs:112-117
+  const float cos_theta = std::fmin((-v).dot(n), 1.0f);
+  const Vec3 r_out_perp = etai_over_etat * (v + cos_theta * n);
+  const Vec3 r_out_parallel = (-std::sqrt(std::fabs(1.0f - r_out_perp.length_squared()))) * n;
+  return r_out_perp + r_out_parallel;
+}
+
+// ---------------------------------------------------------------------------
+// ray.rs
+// ---------------------------------------------------------------------------
+struct Ray {
+  Point3 origin;
+  Vec3 direction;
+  float time = 0.0f;
+  Ray() = default;
+  Ray(Point3 o, Vec3 d, float t) : origin(o), direction(d), time(t) {}
+  Vec3 at(float t) const { return origin + direction * t; }  // ray.rs:19-21
+};
+
+// ---------------------------------------------------------------------------
+// aabb.rs
+// ---------------------------------------------------------------------------
+struct AABB {
+  Point3 minimum, maximum;
+  AABB() = default;
+  AABB(Point3 a, Point3 b) : minimum(a), maximum(b) {}
+
+  // aabb.rs:41-51.  The interval is widened (min with t_min, max with t_max),
+  // not narrowed, exactly as the reference does.
+  static bool hit_check(float mn, float mx, float dir, float orig, float t_min, float t_max) {
+    const float inv = 1.0f / dir;
+    float t0 = (mn - orig) * inv;
+    float t1 = (mx - orig) * inv;
+    if (inv < 0.0f) std::swap(t0, t1);
+    t_min = std::fmin(t0, t_min);  // f32::min ignores NaN, as fminf does
+    t_max = std::fmax(t1, t_max);
+    return t_max > t_min;
+  }
+  bool hit(const Ray& r, float t_min, float t_max) const {  // aabb.rs:15-38
+    return hit_check(minimum.x, maximum.x, r.direction.x, r.origin.x, t_min, t_max) ||
+           hit_check(minimum.y, maximum.y, r.direction.y, r.origin.y, t_min, t_max) ||
+           hit_check(minimum.z, maximum.z, r.direction.z, r.origin.z, t_min, t_max);
+  }
+  static AABB surrounding_box(const AABB& a, const AABB& b) {  // aabb.rs:53-65
+    return AABB(Point3(std::fmin(a.minimum.x, b.minimum.x), std::fmin(a.minimum.y, b.minimum.y),
+                       std::fmin(a.minimum.z, b.minimum.z)),
+                Point3(std::fmax(a.maximum.x, b.maximum.x), std::fmax(a.maximum.y, b.maximum.y),
+                       std::fmax(a.maximum.z, b.maximum.z)));
+  }
+};
+
+// ---------------------------------------------------------------------------
+// onb.rs
+// ---------------------------------------------------------------------------
+struct Onb {
+  Vec3 u, v, w;
+  static Onb new_from_w(const Vec3& n) {  // onb.rs:10-20
+    Onb o;
+    o.w = n.unit();
+    const Vec3 a = std::fabs(o.w.x) > 0.9f ? Vec3(0.0f, 1.0f, 0.0f) : Vec3(1.0f, 0.0f, 0.0f);
+    o.v = o.w.cross(a).unit();
+    o.u = o.w.cross(o.v);
+    return o;
+  }
+  Vec3 local_from_vec(const Vec3& a) const {  // onb.rs:26-28
+    return a.x * u + a.y * v + a.z * w;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// perlin.rs
+// ---------------------------------------------------------------------------
+// Scene-construction randomness (Perlin tables, sphere positions, box heights)
+// comes from a small seeded generator, consumed in source order.
+struct SceneRng {
+  uint64_t state;
+  explicit SceneRng(uint64_t seed) : state(seed) {}
+  uint64_t next_u64() {  // splitmix64
+    uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  float uniform01() { return (float)(next_u64() >> 40) * (1.0f / 16777216.0f); }
+  float uniform(float lo, float hi) { return lo + (hi - lo) * uniform01(); }
+  uint32_t below(uint32_t n) { return (uint32_t)(((next_u64() >> 32) * (uint64_t)n) >> 32); }  // [0,n)
+  Vec3 vec3(float lo, float hi) {
+    const float x = uniform(lo, hi), y = uniform(lo, hi), z = uniform(lo, hi);
+    return Vec3(x, y, z);
+  }
+};
+
+struct Perlin {
+  static constexpr uint32_t POINT_COUNT = 256;
+  std::vector<Vec3> random_vec;
+  std::vector<uint32_t> perm_x, perm_y, perm_z;
+
+  explicit Perlin(SceneRng& rng) {  // perlin.rs:12-23
+    random_vec.reserve(POINT_COUNT);
+    for (uint32_t i = 0; i < POINT_COUNT; ++i) random_vec.push_back(rng.vec3(-1.0f, 1.0f).unit());
+    perm_x = generate_perm(rng);
+    perm_y = generate_perm(rng);
+    perm_z = generate_perm(rng);
+  }
+  static std::vector<uint32_t> generate_perm(SceneRng& rng) {  // perlin.rs:62-73
+    std::vector<uint32_t> p(POINT_COUNT);
+    for (uint32_t i = 0; i < POINT_COUNT; ++i) p[i] = i;
+    for (uint32_t i = POINT_COUNT - 1; i >= 1; --i) {
+      const uint32_t target = rng.below(i);  // Uniform::new(0, i): upper bound exclusive
+      std::swap(p[i], p[target]);
+    }
+    return p;
+  }
+  float noise(const Point3& p) const {  // perlin.rs:26-48
+    const float u = p.x - std::floor(p.x);
+    const float v = p.y - std::floor(p.y);
+    const float w = p.z - std::floor(p.z);
+    const int32_t i = (int32_t)std::floor(p.x);
+    const int32_t j = (int32_t)std::floor(p.y);
+    const int32_t k = (int32_t)std::floor(p.z);
+    Vec3 c[2][2][2];
+    for (int di = 0; di < 2; ++di)
+      for (int dj = 0; dj < 2; ++dj)
+        for (int dk = 0; dk < 2; ++dk)
+          c[di][dj][dk] = random_vec[perm_x[(i + di) & 255] ^ perm_y[(j + dj) & 255] ^ perm_z[(k + dk) & 255]];
+    return trilinear_interp(c, u, v, w);
+  }
+  float turb(const Point3& p, uint32_t depth) const {  // perlin.rs:50-60
+    float accum = 0.0f;
+    Vec3 tmp = p;
+    float weight = 1.0f;
+    for (uint32_t i = 0; i < depth; ++i) {
+      accum += weight * noise(tmp);
+      weight *= 0.5f;
+      tmp = tmp * 2.0f;
+    }
+    return std::fabs(accum);
+  }
+  static float trilinear_interp(const Vec3 c[2][2][2], float u, float v, float w) {  // perlin.rs:75-93
+    const float uu = u * u * (3.0f - 2.0f * u);
+    const float vv = v * v * (3.0f - 2.0f * v);
+    const float ww = w * w * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 2; ++k) {
+          const Vec3 weight(u - (float)i, v - (float)j, w - (float)k);
+          accum += ((float)i * uu + (1.0f - (float)i) * (1.0f - uu)) *
+                   ((float)j * vv + (1.0f - (float)j) * (1.0f - vv)) *
+                   ((float)k * ww + (1.0f - (float)k) * (1.0f - ww)) * c[i][j][k].dot(weight);
+        }
+    return accum;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// texture.rs
+// ---------------------------------------------------------------------------
+struct SolidTexture {
+  Color c;
+  SolidTexture() = default;
+  explicit SolidTexture(Color c_) : c(c_) {}
+  static SolidTexture from_rgb(float r, float g, float b) { return SolidTexture(Color(r, g, b)); }
+  Color color(float, float, const Point3&) const { return c; }  // texture.rs:25-29
+};
+
+template <class O, class E>
+struct CheckerTexture {
+  O odd;
+  E even;
+  CheckerTexture(O o, E e) : odd(std::move(o)), even(std::move(e)) {}
+  Color color(float u, float v, const Point3& p) const {  // texture.rs:51-60
+    const float sines = std::sin(10.0f * p.x) * std::sin(10.0f * p.y) * std::sin(10.0f * p.z);
+    return sines < 0.0f ? odd.color(u, v, p) : even.color(u, v, p);
+  }
+};
+inline CheckerTexture<SolidTexture, SolidTexture> checker_from_colors(Color odd, Color even) {
+  return CheckerTexture<SolidTexture, SolidTexture>(SolidTexture(odd), SolidTexture(even));
+}
+
+struct NoiseTexture {
+  std::shared_ptr<Perlin> noise;
+  float scale;
+  NoiseTexture(float scale_, SceneRng& rng) : noise(std::make_shared<Perlin>(rng)), scale(scale_) {}
+  Color color(float, float, const Point3& p) const {  // texture.rs:76-82 (turbulence depth 2)
+    return Color(1.0f, 1.0f, 1.0f) * 0.5f * (1.0f + std::sin(scale * p.z + 10.0f * noise->turb(p, 2)));
+  }
+};
+
+inline uint32_t to_u32_saturating(float v) {  // Rust `as u32`: NaN -> 0, saturating
+  if (!(v == v) || v <= 0.0f) return 0;
+  if (v >= 4294967040.0f) return 0xFFFFFFFFu;
+  return (uint32_t)v;
+}
+
+struct ImageTexture {
+  std::shared_ptr<std::vector<uint8_t>> data;  // RGB8, row 0 = image top
+  uint32_t width = 0, height = 0;
+  ImageTexture(std::shared_ptr<std::vector<uint8_t>> d, uint32_t w, uint32_t h)
+      : data(std::move(d)), width(w), height(h) {}
+  Color color(float u, float v, const Point3&) const {  // texture.rs:101-122
+    u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+    v = 1.0f - (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
+    uint32_t i = to_u32_saturating(u * (float)width);
+    uint32_t j = to_u32_saturating(v * (float)height);
+    if (i >= width) i = width - 1;
+    if (j >= height) j = height - 1;
+    const float color_scale = 1.0f / 255.0f;
+    const size_t pixel = (size_t)j * width * 3 + (size_t)i * 3;
+    return Color(color_scale * (float)(*data)[pixel], color_scale * (float)(*data)[pixel + 1],
+                 color_scale * (float)(*data)[pixel + 2]);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// hittable.rs / material.rs / pdf.rs interfaces
+// ---------------------------------------------------------------------------
+struct Material;
+
+struct HitRecord {  // hittable.rs:8-16
+  Point3 point;
+  Vec3 normal;
+  const Material* material = nullptr;
+  float t = 0.0f, u = 0.0f, v = 0.0f;
+  bool front_face = false;
+
+  static HitRecord make(Point3 point, float t, float u, float v, const Material* m, const Ray& ray,
+                        const Vec3& outward_normal) {  // hittable.rs:19-42
+    HitRecord h;
+    h.front_face = ray.direction.dot(outward_normal) < 0.0f;
+    h.point = point;
+    h.normal = h.front_face ? outward_normal : -outward_normal;
+    h.material = m;
+    h.t = t; h.u = u; h.v = v;
+    return h;
+  }
+};
+
+struct Hittable {  // hittable.rs:49-58
+  virtual ~Hittable() = default;
+  virtual bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const = 0;
+  virtual AABB bounding_box() const = 0;
+  virtual float pdf_value(const Point3&, const Vec3&) const { return 0.0f; }
+  virtual Vec3 random(const Vec3&) const { return Vec3(1.0f, 0.0f, 0.0f); }
+  // Not in the reference: numbers the constant media of a scene in scan order
+  // so each one reads its own free-flight draw of the STAGE_MEDIA stream.
+  virtual void number_media(uint32_t&) {}
+};
+
+struct Pdf {  // pdf.rs:7-10
+  virtual ~Pdf() = default;
+  virtual float value(const Vec3& direction) const = 0;
+  virtual Vec3 generate() const = 0;
+};
+
+struct CosinePdf final : Pdf {  // pdf.rs:12-37
+  Onb uvw;
+  explicit CosinePdf(const Vec3& w) : uvw(Onb::new_from_w(w)) {}
+  float value(const Vec3& direction) const override {
+    const float cosine = direction.unit().dot(uvw.w);
+    return cosine <= 0.0f ? 0.0f : cosine / PI_F;
+  }
+  Vec3 generate() const override { return uvw.local_from_vec(random_cosine_direction()); }
+};
+
+struct HittablePdf final : Pdf {  // pdf.rs:39-67
+  const Hittable* object;
+  Point3 origin;
+  HittablePdf(const Hittable* o, Point3 p) : object(o), origin(p) {}
+  float value(const Vec3& direction) const override { return object->pdf_value(origin, direction); }
+  Vec3 generate() const override { return object->random(origin); }
+};
+
+struct MixturePdf final : Pdf {  // pdf.rs:69-92
+  const Pdf* pdf1;
+  const Pdf* pdf2;
+  MixturePdf(const Pdf* a, const Pdf* b) : pdf1(a), pdf2(b) {}
+  float value(const Vec3& direction) const override {
+    return 0.5f * pdf1->value(direction) + 0.5f * pdf2->value(direction);
+  }
+  Vec3 generate() const override {
+    // gen_bool(0.5): true with probability one half
+    return rand01() < 0.5f ? pdf1->generate() : pdf2->generate();
+  }
+};
+
+struct ScatterRecord {  // material.rs:9-14
+  Ray specular_ray;
+  bool is_specular = false;
+  Color attenuation;
+  std::unique_ptr<Pdf> pdf;
+};
+
+struct Material {  // material.rs:16-26
+  virtual ~Material() = default;
+  virtual bool scatter(const Ray&, const HitRecord&, ScatterRecord&) const { return false; }
+  virtual float scattering_pdf(const Ray&, const HitRecord&, const Ray&) const { return 0.0f; }
+  virtual Color emit(const Ray&, const HitRecord&, float, float, const Point3&) const { return Color(); }
+};
+
+template <class T>
+struct Lambertian final : Material {  // material.rs:28-58
+  T albedo;
+  explicit Lambertian(T a) : albedo(std::move(a)) {}
+  bool scatter(const Ray&, const HitRecord& h, ScatterRecord& s) const override {
+    s.is_specular = false;
+    s.attenuation = albedo.color(h.u, h.v, h.point);
+    s.pdf = std::make_unique<CosinePdf>(h.normal);
+    return true;
+  }
+  float scattering_pdf(const Ray&, const HitRecord& h, const Ray& scattered) const override {
+    const float cosine = h.normal.dot(scattered.direction.unit());
+    return cosine < 0.0f ? 0.0f : cosine / PI_F;
+  }
+};
+
+template <class T>
+struct Metal final : Material {  // material.rs:60-91
+  T albedo;
+  float fuzz;
+  Metal(T a, float f) : albedo(std::move(a)), fuzz(f < 1.0f ? f : 1.0f) {}
+  bool scatter(const Ray& ray, const HitRecord& h, ScatterRecord& s) const override {
+    const Vec3 reflected = reflect(ray.direction.unit(), h.normal);
+    s.specular_ray = Ray(h.point, reflected + fuzz * random_in_unit_sphere(), ray.time);
+    s.attenuation = albedo.color(h.u, h.v, h.point);
+    s.is_specular = true;
+    return true;
+  }
+};
+
+struct Dielectric final : Material {  // material.rs:93-138
+  float index_of_refraction;
+  explicit Dielectric(float ior) : index_of_refraction(ior) {}
+  static float reflectance(float cosine, float ref_idx) {  // material.rs:105-108
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    const float m = 1.0f - cosine;
+    // powi(5): LLVM expands x^5 as (x^2)^2 * x
+    const float m2 = m * m;
+    return r0 + (1.0f - r0) * (m2 * m2 * m);
+  }
+  bool scatter(const Ray& ray, const HitRecord& h, ScatterRecord& s) const override {
+    const float refraction_ratio = h.front_face ? 1.0f / index_of_refraction : index_of_refraction;
+    const Vec3 unit_direction = ray.direction.unit();
+    const float cos_theta = std::fmin((-unit_direction).dot(h.normal), 1.0f);
+    const float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+    Vec3 direction;
+    // `||` short-circuits: no draw under total internal reflection
+    if (refraction_ratio * sin_theta > 1.0f || reflectance(cos_theta, refraction_ratio) > rand01()) {
+      direction = reflect(unit_direction, h.normal);
+    } else {
+      direction = refract(unit_direction, h.normal, refraction_ratio);
+    }
+    s.specular_ray = Ray(h.point, direction, ray.time);
+    s.is_specular = true;
+    s.attenuation = Color(1.0f, 1.0f, 1.0f);
+    return true;
+  }
+};
+
+template <class T>
+struct DiffuseLight final : Material {  // material.rs:140-159
+  T emit_tex;
+  explicit DiffuseLight(T e) : emit_tex(std::move(e)) {}
+  Color emit(const Ray&, const HitRecord& h, float u, float v, const Point3& p) const override {
+    return h.front_face ? emit_tex.color(u, v, p) : Color();
+  }
+};
+
+template <class T>
+struct Isotropic final : Material {  // material.rs:161-180: no scatter impl, so it absorbs
+  T albedo;
+  explicit Isotropic(T a) : albedo(std::move(a)) {}
+};
+
+// ---------------------------------------------------------------------------
+// objects.rs
+// ---------------------------------------------------------------------------
+inline void get_sphere_uv(const Point3& p, float& u, float& v) {  // objects.rs:17-28
+  const float theta = std::acos(-p.y);
+  const float phi = -std::atan2(p.z, p.x) + PI_F;
+  u = phi / (2.0f * PI_F);
+  v = theta / PI_F;
+}
+
+// Shared body of Sphere::hit / MovingSphere::hit (objects.rs:41-73, 138-171).
+inline bool sphere_hit_common(const Point3& center, float radius, const Material* m, const Ray& ray,
+                              float t_min, float t_max, HitRecord& out) {
+  const Vec3 os = ray.origin - center;
+  const float a = ray.direction.length_squared();
+  const float half_b = os.dot(ray.direction);
+  const float c = os.length_squared() - radius * radius;
+  const float discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0f) return false;
+  const float sqrtd = std::sqrt(discriminant);
+  float root = (-half_b - sqrtd) / a;
+  if (root < t_min || root > t_max) {
+    root = (-half_b + sqrtd) / a;
+    if (root < t_min || root > t_max) return false;
+  }
+  const Point3 point = ray.at(root);
+  const Vec3 outward_normal = (point - center) / radius;
+  float u, v;
+  get_sphere_uv(outward_normal, u, v);
+  out = HitRecord::make(point, root, u, v, m, ray, outward_normal);
+  return true;
+}
+
+template <class M>
+struct Sphere final : Hittable {
+  Point3 center;
+  float radius;
+  M material;
+  Sphere(Point3 c, float r, M m) : center(c), radius(r), material(std::move(m)) {}
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    return sphere_hit_common(center, radius, &material, ray, t_min, t_max, out);
+  }
+  AABB bounding_box() const override {  // objects.rs:75-80
+    return AABB(center - Vec3(radius, radius, radius), center + Vec3(radius, radius, radius));
+  }
+  float pdf_value(const Point3& origin, const Vec3& direction) const override {  // objects.rs:82-94
+    HitRecord tmp;
+    if (hit(Ray(origin, direction, 0.0f), 0.001f, INF_F, tmp)) {
+      const float cos_theta_max = std::sqrt(1.0f - radius * radius / (center - origin).length_squared());
+      const float solid_angle = 2.0f * PI_F * (1.0f - cos_theta_max);
+      return 1.0f / solid_angle;
+    }
+    return 0.0f;
+  }
+  Vec3 random(const Vec3& origin) const override {  // objects.rs:96-100
+    const Vec3 dir = center - origin;
+    const Onb uvw = Onb::new_from_w(dir);
+    return uvw.local_from_vec(random_to_sphere(radius, dir.length_squared()));
+  }
+};
+
+template <class M>
+struct MovingSphere final : Hittable {
+  Point3 center0, center1;
+  float time0, time1, radius;
+  M material;
+  MovingSphere(Point3 c0, Point3 c1, float t0, float t1, float r, M m)
+      : center0(c0), center1(c1), time0(t0), time1(t1), radius(r), material(std::move(m)) {}
+  Point3 center(float time) const {  // objects.rs:132-135
+    return center0 + ((time - time0) / (time1 - time0)) * (center1 - center0);
+  }
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    return sphere_hit_common(center(ray.time), radius, &material, ray, t_min, t_max, out);
+  }
+  AABB bounding_box() const override {  // objects.rs:173-180
+    const Vec3 r(radius, radius, radius);
+    return AABB::surrounding_box(AABB(center0 - r, center0 + r), AABB(center1 - r, center1 + r));
+  }
+};
+
+template <class M>
+struct XYRect final : Hittable {  // objects.rs:183-236
+  float x0, x1, y0, y1, k;
+  M material;
+  XYRect(float x0_, float x1_, float y0_, float y1_, float k_, M m)
+      : x0(x0_), x1(x1_), y0(y0_), y1(y1_), k(k_), material(std::move(m)) {}
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    const float t = (k - ray.origin.z) / ray.direction.z;
+    if (t < t_min || t > t_max) return false;
+    const float x = ray.origin.x + t * ray.direction.x;
+    const float y = ray.origin.y + t * ray.direction.y;
+    if (x < x0 || x > x1 || y < y0 || y > y1) return false;
+    const float u = (x - x0) / (x1 - x0);
+    const float v = (y - y0) / (y1 - y0);
+    out = HitRecord::make(ray.at(t), t, u, v, &material, ray, Vec3(0.0f, 0.0f, 1.0f));
+    return true;
+  }
+  AABB bounding_box() const override {
+    return AABB(Point3(x0, y0, k - 0.00001f), Point3(x1, y1, k + 0.00001f));
+  }
+};
+
+template <class M>
+struct XZRect final : Hittable {  // objects.rs:238-310
+  float x0, x1, z0, z1, k;
+  M material;
+  XZRect(float x0_, float x1_, float z0_, float z1_, float k_, M m)
+      : x0(x0_), x1(x1_), z0(z0_), z1(z1_), k(k_), material(std::move(m)) {}
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    const float t = (k - ray.origin.y) / ray.direction.y;
+    if (t < t_min || t > t_max) return false;
+    const float x = ray.origin.x + t * ray.direction.x;
+    const float z = ray.origin.z + t * ray.direction.z;
+    if (x < x0 || x > x1 || z < z0 || z > z1) return false;
+    const float u = (x - x0) / (x1 - x0);
+    const float v = (z - z0) / (z1 - z0);
+    out = HitRecord::make(ray.at(t), t, u, v, &material, ray, Vec3(0.0f, 1.0f, 0.0f));
+    return true;
+  }
+  AABB bounding_box() const override {
+    return AABB(Point3(x0, k - 0.00001f, z0), Point3(x1, k + 0.00001f, z1));
+  }
+  float pdf_value(const Point3& origin, const Vec3& direction) const override {  // objects.rs:292-301
+    HitRecord h;
+    if (hit(Ray(origin, direction, 0.0f), 0.0001f, INF_F, h)) {
+      const float area = (x1 - x0) * (z1 - z0);
+      const float dist_sqrt = h.t * h.t * direction.length_squared();
+      const float cosine = std::fabs(direction.dot(h.normal) / direction.length());
+      return dist_sqrt / (cosine * area);
+    }
+    return 0.0f;
+  }
+  Vec3 random(const Vec3& origin) const override {  // objects.rs:302-309
+    const float rx = rand_range(x0, x1);
+    const float rz = rand_range(z0, z1);
+    return Point3(rx, k, rz) - origin;
+  }
+};
+
+template <class M>
+struct YZRect final : Hittable {  // objects.rs:312-365
+  float y0, y1, z0, z1, k;
+  M material;
+  YZRect(float y0_, float y1_, float z0_, float z1_, float k_, M m)
+      : y0(y0_), y1(y1_), z0(z0_), z1(z1_), k(k_), material(std::move(m)) {}
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    const float t = (k - ray.origin.x) / ray.direction.x;
+    if (t < t_min || t > t_max) return false;
+    const float y = ray.origin.y + t * ray.direction.y;
+    const float z = ray.origin.z + t * ray.direction.z;
+    if (y < y0 || y > y1 || z < z0 || z > z1) return false;
+    const float u = (y - y0) / (y1 - y0);
+    const float v = (z - z0) / (z1 - z0);
+    out = HitRecord::make(ray.at(t), t, u, v, &material, ray, Vec3(1.0f, 0.0f, 0.0f));
+    return true;
+  }
+  AABB bounding_box() const override {
+    return AABB(Point3(k - 0.00001f, y0, z0), Point3(k + 0.00001f, y1, z1));
+  }
+};
+
+template <class M>
+struct Box3d final : Hittable {  // objects.rs:367-441
+  Point3 min, max;
+  XYRect<M> xy_min, xy_max;
+  XZRect<M> xz_min, xz_max;
+  YZRect<M> yz_min, yz_max;
+  Box3d(Point3 mn, Point3 mx, M m)
+      : min(mn), max(mx),
+        xy_min(mn.x, mx.x, mn.y, mx.y, mx.z, m),  // sits at max.z, as in the reference
+        xy_max(mn.x, mx.x, mn.y, mx.y, mn.z, m),
+        xz_min(mn.x, mx.x, mn.z, mx.z, mn.y, m),
+        xz_max(mn.x, mx.x, mn.z, mx.z, mx.y, m),
+        yz_min(mn.y, mx.y, mn.z, mx.z, mn.x, m),
+        yz_max(mn.y, mx.y, mn.z, mx.z, mx.x, m) {}
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    bool hit_anything = false;
+    float closest = t_max;
+    HitRecord rec;
+    const Hittable* sides[6] = {&xy_min, &xy_max, &xz_min, &xz_max, &yz_min, &yz_max};
+    for (const Hittable* s : sides) {
+      if (s->hit(ray, t_min, closest, rec)) {
+        hit_anything = true;
+        closest = rec.t;
+        out = rec;
+      }
+    }
+    return hit_anything;
+  }
+  AABB bounding_box() const override { return AABB(min, max); }
+};
+
+// ---------------------------------------------------------------------------
+// transforms.rs
+// ---------------------------------------------------------------------------
+template <class T>
+struct Translate final : Hittable {  // transforms.rs:3-30
+  T object;
+  Vec3 offset;
+  Translate(T o, Vec3 off) : object(std::move(o)), offset(off) {}
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    const Ray moved(ray.origin - offset, ray.direction, ray.time);
+    if (!object.hit(moved, t_min, t_max, out)) return false;
+    out.point += offset;
+    out.front_face = moved.direction.dot(out.normal) < 0.0f;  // normal itself is left as is
+    return true;
+  }
+  AABB bounding_box() const override {
+    const AABB b = object.bounding_box();
+    return AABB(b.minimum + offset, b.maximum + offset);
+  }
+  void number_media(uint32_t& n) override { object.number_media(n); }
+};
+
+inline float to_radians(float deg) { return deg * (PI_F / 180.0f); }
+
+template <class T>
+struct Rotate final : Hittable {  // transforms.rs:32-115 (about the Y axis)
+  T object;
+  float sin_theta, cos_theta;
+  AABB aabb;
+  Rotate(T o, float angle) : object(std::move(o)) {
+    const float radians = to_radians(angle);
+    sin_theta = std::sin(radians);
+    cos_theta = std::cos(radians);
+    const AABB b = object.bounding_box();
+    Point3 mn(INF_F, INF_F, INF_F), mx(-INF_F, -INF_F, -INF_F);
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j)
+        for (int k = 0; k < 2; ++k) {
+          const float x = (float)i * b.maximum.x + (1.0f - (float)i) * b.minimum.x;
+          const float y = (float)j * b.maximum.y + (1.0f - (float)j) * b.minimum.y;
+          const float z = (float)k * b.maximum.z + (1.0f - (float)k) * b.minimum.z;
+          const float newx = cos_theta * x + sin_theta * z;
+          const float newz = -sin_theta * x + cos_theta * z;
+          mn.x = std::fmin(mn.x, newx); mn.y = std::fmin(mn.y, y); mn.z = std::fmin(mn.z, newz);
+          mx.x = std::fmax(mx.x, newx); mx.y = std::fmax(mx.y, y); mx.z = std::fmax(mx.z, newz);
+        }
+    aabb = AABB(mn, mx);
+  }
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    Point3 origin = ray.origin;
+    Vec3 direction = ray.direction;
+    origin.x = cos_theta * ray.origin.x - sin_theta * ray.origin.z;
+    origin.z = sin_theta * ray.origin.x + cos_theta * ray.origin.z;
+    direction.x = cos_theta * ray.direction.x - sin_theta * ray.direction.z;
+    direction.z = sin_theta * ray.direction.x + cos_theta * ray.direction.z;
+    const Ray rotated(origin, direction, ray.time);
+    if (!object.hit(rotated, t_min, t_max, out)) return false;
+    Point3 point = out.point;
+    Vec3 normal = out.normal;
+    point.x = cos_theta * out.point.x + sin_theta * out.point.z;
+    point.z = -sin_theta * out.point.x + cos_theta * out.point.z;
+    normal.x = cos_theta * out.normal.x + sin_theta * out.normal.z;
+    normal.z = -sin_theta * out.normal.x + cos_theta * out.normal.z;
+    out.point = point;
+    // object-space direction against the world-space normal, as the reference does
+    out.front_face = rotated.direction.dot(normal) < 0.0f;
+    out.normal = out.front_face ? normal : -normal;
+    return true;
+  }
+  AABB bounding_box() const override { return aabb; }
+  void number_media(uint32_t& n) override { object.number_media(n); }
+};
+
+template <class T, class M>
+struct ConstantMedium final : Hittable {  // transforms.rs:117-185
+  T boundary;
+  M phase_function;
+  float neg_inv_density;
+  uint32_t ordinal = 0;
+  ConstantMedium(T b, float density, M m)
+      : boundary(std::move(b)), phase_function(std::move(m)), neg_inv_density(-1.0f / density) {}
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    HitRecord hit1, hit2;
+    if (!boundary.hit(ray, -INF_F, INF_F, hit1)) return false;
+    if (!boundary.hit(ray, hit1.t + 0.0001f, INF_F, hit2)) return false;
+    if (hit1.t < t_min) hit1.t = t_min;
+    if (hit2.t > t_max) hit2.t = t_max;
+    if (hit1.t >= hit2.t) return false;
+    if (hit1.t < 0.0f) hit1.t = 0.0f;
+    const float ray_length = ray.direction.length();
+    const float distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
+    // rand::random::<f32>().log2() -- log2, not ln.  Medium number `ordinal`
+    // reads draw `ordinal` of the STAGE_MEDIA stream of this bounce.
+    const float hit_distance = neg_inv_density * std::log2(tls_sampler()->at(ordinal));
+    if (hit_distance > distance_inside_boundary) return false;
+    const float t = hit1.t + hit_distance / ray_length;
+    out.point = ray.at(t);
+    out.normal = Vec3(1.0f, 0.0f, 0.0f);
+    out.material = &phase_function;
+    out.t = t; out.u = 0.0f; out.v = 0.0f;
+    out.front_face = true;
+    return true;
+  }
+  AABB bounding_box() const override { return boundary.bounding_box(); }
+  void number_media(uint32_t& n) override { ordinal = n++; }
+};
+
+template <class T>
+struct FlipFace final : Hittable {  // transforms.rs:187-210
+  T object;
+  explicit FlipFace(T o) : object(std::move(o)) {}
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    if (!object.hit(ray, t_min, t_max, out)) return false;
+    out.front_face = !out.front_face;
+    return true;
+  }
+  AABB bounding_box() const override { return object.bounding_box(); }
+  void number_media(uint32_t& n) override { object.number_media(n); }
+};
+
+// ---------------------------------------------------------------------------
+// world.rs
+// ---------------------------------------------------------------------------
+struct WorldIndex {  // world.rs:13-17
+  uint32_t type_index = 0, object_index = 0;
+};
+
+struct World final : Hittable {
+  AABB aabb;  // starts as the default (0,0,0)-(0,0,0) box, world.rs:19-24
+  std::vector<std::type_index> types;  // first-add order == column order of `data`
+  std::vector<std::vector<std::shared_ptr<Hittable>>> data;
+
+  World() = default;
+  World(World&&) = default;
+  World& operator=(World&&) = default;
+
+  template <class T>
+  void add(T object) {  // world.rs:27-40: one column per concrete type
+    const std::type_index id(typeid(T));
+    size_t index = 0;
+    for (; index < types.size(); ++index)
+      if (types[index] == id) break;
+    if (index == types.size()) {
+      types.push_back(id);
+      data.emplace_back();
+    }
+    aabb = AABB::surrounding_box(aabb, object.bounding_box());
+    data[index].push_back(std::make_shared<T>(std::move(object)));
+  }
+  // world.rs:42-59.  The reference iterates a HashMap (order random per
+  // process); here columns are visited in type_index order.
+  std::vector<std::pair<WorldIndex, AABB>> volumes() const {
+    std::vector<std::pair<WorldIndex, AABB>> v;
+    for (uint32_t ti = 0; ti < data.size(); ++ti)
+      for (uint32_t oi = 0; oi < data[ti].size(); ++oi)
+        v.push_back({WorldIndex{ti, oi}, data[ti][oi]->bounding_box()});
+    return v;
+  }
+  bool hit_object(const WorldIndex& idx, const Ray& ray, float t_min, float t_max, HitRecord& out) const {
+    return data[idx.type_index][idx.object_index]->hit(ray, t_min, t_max, out);  // world.rs:61-72
+  }
+  // Same scan as hit(), also reporting which object won (for id checks).
+  bool hit_indexed(const Ray& ray, float t_min, float t_max, HitRecord& out, WorldIndex& who) const {
+    bool hit_anything = false;
+    float closest = t_max;
+    HitRecord rec;
+    for (uint32_t ti = 0; ti < data.size(); ++ti)
+      for (uint32_t oi = 0; oi < data[ti].size(); ++oi)
+        if (data[ti][oi]->hit(ray, t_min, closest, rec)) {
+          hit_anything = true;
+          closest = rec.t;
+          out = rec;
+          who = WorldIndex{ti, oi};
+        }
+    return hit_anything;
+  }
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {  // world.rs:75-94
+    WorldIndex who;
+    return hit_indexed(ray, t_min, t_max, out, who);
+  }
+  AABB bounding_box() const override { return aabb; }
+  float pdf_value(const Point3& origin, const Vec3& direction) const override {  // world.rs:100-110
+    size_t total = 0;
+    for (const auto& col : data) total += col.size();
+    const float weight = 1.0f / (float)total;
+    float sum = 0.0f;
+    for (const auto& col : data)
+      for (const auto& obj : col) sum += weight * obj->pdf_value(origin, direction);
+    return sum;
+  }
+  Vec3 random(const Vec3& origin) const override {  // world.rs:112-117: type first, then object
+    const uint32_t nt = (uint32_t)data.size();
+    uint32_t ti = (uint32_t)(rand01() * (float)nt);
+    if (ti >= nt) ti = nt - 1;
+    const uint32_t no = (uint32_t)data[ti].size();
+    uint32_t oi = (uint32_t)(rand01() * (float)no);
+    if (oi >= no) oi = no - 1;
+    return data[ti][oi]->random(origin);
+  }
+  void number_media(uint32_t& n) override {
+    for (auto& col : data)
+      for (auto& obj : col) obj->number_media(n);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// bvh.rs
+// ---------------------------------------------------------------------------
+struct BVH final : Hittable {
+  struct Child {  // BVHNIndex, bvh.rs:7-10
+    bool is_node = false;
+    size_t node = 0;
+    WorldIndex index;
+    AABB aabb;
+  };
+  struct Node {  // BVHNode2, bvh.rs:12-16
+    Child left, right;
+    AABB aabb;
+  };
+  World world;
+  std::vector<Node> nodes;
+
+  static BVH from_world(World w, float time0, float time1) {  // bvh.rs:24-29
+    BVH b;
+    b.world = std::move(w);
+    auto volumes = b.world.volumes();
+    create_node(b.nodes, volumes.data(), volumes.size(), 0, time0, time1);
+    return b;
+  }
+  static float axis_key(const std::pair<WorldIndex, AABB>& v, int axis) {  // bvh.rs:82-90
+    return axis == 0 ? v.second.minimum.x : (axis == 1 ? v.second.minimum.y : v.second.minimum.z);
+  }
+  static Child create_node(std::vector<Node>& nodes, std::pair<WorldIndex, AABB>* vols, size_t n, int axis,
+                           float time0, float time1) {  // bvh.rs:31-81
+    const int cmp_axis = axis;
+    axis = (axis + 1) % 3;
+    auto leaf = [](const std::pair<WorldIndex, AABB>& v) {
+      Child c; c.is_node = false; c.index = v.first; c.aabb = v.second; return c;
+    };
+    Child left, right;
+    if (n == 1) return leaf(vols[0]);
+    if (n == 2) {
+      // Less -> (0,1); Greater -> (1,0); Equal -> (0,1)
+      if (axis_key(vols[0], cmp_axis) > axis_key(vols[1], cmp_axis)) {
+        left = leaf(vols[1]); right = leaf(vols[0]);
+      } else {
+        left = leaf(vols[0]); right = leaf(vols[1]);
+      }
+    } else {
+      std::stable_sort(vols, vols + n, [cmp_axis](const auto& a, const auto& b) {
+        return axis_key(a, cmp_axis) < axis_key(b, cmp_axis);
+      });
+      const size_t half = n / 2;
+      left = create_node(nodes, vols, half, axis, time0, time1);
+      right = create_node(nodes, vols + half, n - half, axis, time0, time1);
+    }
+    const AABB lb = left.is_node ? nodes[left.node].aabb : left.aabb;
+    const AABB rb = right.is_node ? nodes[right.node].aabb : right.aabb;
+    Node nd; nd.left = left; nd.right = right; nd.aabb = AABB::surrounding_box(lb, rb);
+    nodes.push_back(nd);
+    Child c; c.is_node = true; c.node = nodes.size() - 1;
+    return c;
+  }
+  // bvh.rs:92-145: returns the surviving candidate leaf of the subtree (or null).
+  const Child* check_node(size_t index, const Ray& ray, float t_min, float t_max) const {
+    const Node& node = nodes[index];
+    if (!node.aabb.hit(ray, t_min, t_max)) return nullptr;
+    const Child* l = node.left.is_node ? check_node(node.left.node, ray, t_min, t_max) : &node.left;
+    const Child* r = node.right.is_node ? check_node(node.right.node, ray, t_min, t_max) : &node.right;
+    if (l && r) {
+      const bool lb = l->aabb.hit(ray, t_min, t_max);
+      const bool rb = r->aabb.hit(ray, t_min, t_max);
+      if (lb && rb) {
+        HitRecord lh, rh;
+        const bool lhit = world.hit_object(l->index, ray, t_min, t_max, lh);
+        const bool rhit = world.hit_object(r->index, ray, t_min, t_max, rh);
+        if (lhit && rhit) return lh.t < rh.t ? l : r;  // ties go right
+        if (lhit) return l;
+        if (rhit) return r;
+        return nullptr;
+      }
+      // bvh.rs:133-134 as written: (false,true) => left, (true,false) => right
+      if (!lb && rb) return l;
+      if (lb && !rb) return r;
+      return nullptr;
+    }
+    if (l) return l;
+    if (r) return r;
+    return nullptr;
+  }
+  bool hit_indexed(const Ray& ray, float t_min, float t_max, HitRecord& out, WorldIndex& who) const {
+    const Child* c = check_node(nodes.size() - 1, ray, t_min, t_max);  // bvh.rs:149-152
+    if (!c) return false;
+    who = c->index;
+    return world.hit_object(c->index, ray, t_min, t_max, out);
+  }
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    WorldIndex who;
+    return hit_indexed(ray, t_min, t_max, out, who);
+  }
+  AABB bounding_box() const override { return nodes[nodes.size() - 1].aabb; }
+  void number_media(uint32_t& n) override { world.number_media(n); }
+};
+
+// ---------------------------------------------------------------------------
+// camera.rs
+// ---------------------------------------------------------------------------
+struct Camera {
+  Point3 origin, lower_left_corner;
+  Vec3 horizontal, vertical, u, v, w;
+  float lens_radius = 0.0f, time0 = 0.0f, time1 = 0.0f;
+
+  Camera() = default;
+  Camera(const Point3& look_from, const Point3& look_at, const Vec3& v_up, float vfov, float aspect_ratio,
+         float aperture, float focus_dist, float time0_, float time1_) {  // camera.rs:19-55
+    const float theta = to_radians(vfov);
+    const float h = std::tan(theta / 2.0f);
+    const float viewport_height = 2.0f * h;
+    const float viewport_width = aspect_ratio * viewport_height;
+    w = (look_from - look_at).unit();
+    u = v_up.cross(w).unit();
+    v = w.cross(u);
+    origin = look_from;
+    horizontal = (focus_dist * viewport_width) * u;
+    vertical = (focus_dist * viewport_height) * v;
+    lower_left_corner = origin - 0.5f * horizontal - 0.5f * vertical - focus_dist * w;
+    lens_radius = aperture / 2.0f;
+    time0 = time0_;
+    time1 = time1_;
+  }
+  Ray get_ray(float x, float y) const {  // camera.rs:57-68
+    const Vec3 rd = lens_radius * random_in_unit_disk();
+    const Vec3 offset = u * rd.x + v * rd.y;
+    const Vec3 dir = lower_left_corner + x * horizontal + y * vertical - origin - offset;
+    const float time = rand_range(time0, time1);
+    return Ray(origin + offset, dir, time);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// renderer.rs
+// ---------------------------------------------------------------------------
+// Segments traced by this thread (mean segments per sample feeds the roofline
+// model in bench.py); not part of the reference.
+inline uint64_t& tls_segments() {
+  thread_local uint64_t n = 0;
+  return n;
+}
+
+// renderer.rs:140-190.  `bounce` counts segments from the camera (0-based);
+// it only selects which Philox stream the draw sites read.
+inline Color ray_color(const Ray& r, const Hittable& world, uint32_t max_depth, uint32_t bounce,
+                       const Color& background, const Hittable* lights) {
+  if (max_depth == 0) return Color(0.0f, 0.0f, 0.0f);
+  ++tls_segments();
+  Sampler* s = tls_sampler();
+  s->begin(bounce, STAGE_MEDIA);
+  HitRecord hit;
+  if (!world.hit(r, 0.001f, INF_F, hit)) return background;
+  s->begin(bounce, STAGE_SHADE);
+  const Color emitted = hit.material->emit(r, hit, hit.u, hit.v, hit.point);
+  ScatterRecord sr;
+  if (!hit.material->scatter(r, hit, sr)) return emitted;
+  if (sr.is_specular)
+    return sr.attenuation * ray_color(sr.specular_ray, world, max_depth - 1, bounce + 1, background, lights);
+  Ray ray;
+  float pdf;
+  if (lights) {
+    const HittablePdf light_pdf(lights, hit.point);
+    const MixturePdf mixture(&light_pdf, sr.pdf.get());
+    ray = Ray(hit.point, mixture.generate(), r.time);
+    pdf = mixture.value(ray.direction);
+  } else {
+    ray = Ray(hit.point, sr.pdf->generate(), r.time);
+    pdf = sr.pdf->value(ray.direction);
+  }
+  const float spdf = hit.material->scattering_pdf(r, hit, ray);
+  const Color child = ray_color(ray, world, max_depth - 1, bounce + 1, background, lights);
+  return emitted + ((sr.attenuation * spdf) * child) / pdf;
+}
+
+inline uint8_t to_u8_saturating(float v) {  // Rust `as u8`: NaN -> 0, saturating
+  if (!(v == v)) return 0;
+  if (v <= 0.0f) return 0;
+  if (v >= 255.0f) return 255;
+  return (uint8_t)v;
+}
+inline float clamp_rust(float v, float lo, float hi) {  // f32::clamp keeps NaN
+  if (v < lo) return lo;
+  if (v > hi) return hi;
+  return v;
+}
+// renderer.rs:232-259 per channel
+inline uint8_t encode_channel(float sum, uint32_t spp) {
+  return to_u8_saturating(255.999f * clamp_rust(std::sqrt(sum / (float)spp), 0.0f, 0.999f));
+}
+
+}  // namespace oracle

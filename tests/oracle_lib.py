@@ -1,0 +1,195 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+ASSET_DIR = ROOT / "raytracing_amd" / "assets"
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", str(ORACLE_DIR)], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = ORACLE_DIR / "liboracle.so"
+    if not so.exists():
+        build()
+    L = C.CDLL(str(so))
+    L.oracle_scene_create.restype = C.c_void_p
+    L.oracle_scene_create.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p]
+    L.oracle_scene_destroy.argtypes = [C.c_void_p]
+    L.oracle_scene_error.restype = C.c_char_p
+    L.oracle_scene_error.argtypes = [C.c_void_p]
+    L.oracle_scene_defaults.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+    L.oracle_scene_camera.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.oracle_scene_object_count.restype = C.c_uint32
+    L.oracle_scene_object_count.argtypes = [C.c_void_p]
+    L.oracle_scene_render.restype = C.c_int
+    L.oracle_scene_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+    L.oracle_scene_trace.restype = C.c_int
+    L.oracle_scene_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    L.oracle_scene_hit_records.restype = C.c_int
+    L.oracle_scene_hit_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
+    L.oracle_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.oracle_kat_hit.restype = C.c_int
+    L.oracle_kat_hit.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    L.oracle_kat_onb.argtypes = [C.c_void_p, C.c_void_p]
+    L.oracle_kat_dielectric.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+    L.oracle_kat_encode.restype = C.c_uint8
+    L.oracle_kat_encode.argtypes = [C.c_float, C.c_uint32]
+    L.oracle_kat_aabb_hit.restype = C.c_int
+    L.oracle_kat_aabb_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Scene:
+    """One of the reference's example scenes, built by the oracle."""
+
+    def __init__(self, name, scene_seed=1, asset_dir=None):
+        self.name = name
+        self.L = lib()
+        self.h = self.L.oracle_scene_create(name.encode(), scene_seed, str(asset_dir or ASSET_DIR).encode())
+        err = self.L.oracle_scene_error(self.h)
+        if err:
+            msg = err.decode()
+            self.close()
+            raise RuntimeError(msg)
+        d = (C.c_uint32 * 4)()
+        a = C.c_float()
+        self.L.oracle_scene_defaults(self.h, d, C.byref(a))
+        self.width, self.height, self.spp, self.depth = (int(x) for x in d)
+        self.aspect = float(a.value)
+
+    def close(self):
+        if self.h:
+            self.L.oracle_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def object_count(self):
+        return int(self.L.oracle_scene_object_count(self.h))
+
+    def camera(self, aspect=0.0):
+        cam = np.zeros(24, np.float32)
+        bg = np.zeros(3, np.float32)
+        self.L.oracle_scene_camera(self.h, aspect, cam.ctypes.data_as(C.POINTER(C.c_float)),
+                                   bg.ctypes.data_as(C.POINTER(C.c_float)))
+        return cam, bg
+
+    def render(self, width, height, spp, depth=None, aspect=0.0, seed=7, first_sample=0, threads=0):
+        """Returns (rgb24 HxWx3 u8, sums HxWx3 f32, segments traced)."""
+        rgb = np.zeros((height, width, 3), np.uint8)
+        sums = np.zeros((height, width, 3), np.float32)
+        stats = np.zeros(1, np.uint64)
+        rc = self.L.oracle_scene_render(self.h, width, height, spp, first_sample,
+                                        self.depth if depth is None else depth, aspect, seed, threads,
+                                        _ptr(rgb), _ptr(sums), _ptr(stats))
+        if rc != 0:
+            raise RuntimeError("oracle render failed")
+        return rgb, sums, int(stats[0])
+
+    def trace(self, rays, seed=7, threads=0):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 7)
+        n = rays.shape[0]
+        ti = np.zeros(n, np.uint32)
+        oi = np.zeros(n, np.uint32)
+        t = np.zeros(n, np.float32)
+        rc = self.L.oracle_scene_trace(self.h, _ptr(rays), n, seed, threads, _ptr(ti), _ptr(oi), _ptr(t))
+        if rc != 0:
+            raise RuntimeError("oracle trace failed")
+        return ti, oi, t
+
+    def hit_records(self, rays, seed=7):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 7)
+        out = np.zeros((rays.shape[0], 12), np.float32)
+        rc = self.L.oracle_scene_hit_records(self.h, _ptr(rays), rays.shape[0], seed, _ptr(out))
+        if rc != 0:
+            raise RuntimeError("oracle hit_records failed")
+        return out
+
+
+def encode(sums, spp):
+    sums = np.ascontiguousarray(sums, np.float32)
+    out = np.zeros(sums.shape, np.uint8)
+    lib().oracle_encode(_ptr(sums), sums.size, spp, _ptr(out))
+    return out
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().oracle_philox(c, k, o)
+    return [int(x) for x in o]
+
+
+def kat_hit(kind, params, ray, t_min=0.001, t_max=float("inf")):
+    p = np.asarray(params, np.float32)
+    r = np.asarray(ray, np.float32)
+    out = np.zeros(10, np.float32)
+    ok = lib().oracle_kat_hit(kind, _ptr(p), _ptr(r), t_min, t_max, _ptr(out))
+    return (ok == 1), out
+
+
+def kat_onb(n):
+    v = np.asarray(n, np.float32)
+    out = np.zeros(9, np.float32)
+    lib().oracle_kat_onb(_ptr(v), _ptr(out))
+    return out.reshape(3, 3)
+
+
+def kat_dielectric(ior, direction, normal, front_face, seed=0):
+    d = np.asarray(direction, np.float32)
+    n = np.asarray(normal, np.float32)
+    out = np.zeros(3, np.float32)
+    lib().oracle_kat_dielectric(ior, _ptr(d), _ptr(n), int(front_face), seed, _ptr(out))
+    return out
+
+
+def pixel_centre_rays(cam, width, height, time=0.5):
+    """Rays through pixel centres, lens offset zero: u=(x+0.5)/(W-1), v=(y+0.5)/(H-1).
+
+    Evaluated in f32 in the operator order of camera.rs:61-62; ray i = y*W + x, y up.
+    """
+    f = np.float32
+    origin, llc, hor, ver = cam[0:3], cam[3:6], cam[6:9], cam[9:12]
+    xs = (np.arange(width, dtype=f) + f(0.5)) / f(width - 1)
+    ys = (np.arange(height, dtype=f) + f(0.5)) / f(height - 1)
+    u = np.tile(xs, height)[:, None]
+    v = np.repeat(ys, width)[:, None]
+    zero = np.zeros(3, f)
+    d = (((llc[None, :] + u * hor[None, :]) + v * ver[None, :]) - origin[None, :]) - zero[None, :]
+    rays = np.zeros((width * height, 7), f)
+    rays[:, 0:3] = origin + zero
+    rays[:, 3:6] = d.astype(f)
+    rays[:, 6] = time
+    return rays
+
+
+def psnr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    mse = np.mean((a - b) ** 2)
+    if mse == 0:
+        return float("inf")
+    return 10.0 * np.log10(255.0 * 255.0 / mse)
