@@ -1,0 +1,173 @@
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace mirt {
+
+namespace {
+
+constexpr int kBins = 16;
+
+struct Box {
+  float mn[3], mx[3];
+  void reset() {
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = std::numeric_limits<float>::infinity();
+      mx[a] = -std::numeric_limits<float>::infinity();
+    }
+  }
+  void grow(const float* bmn, const float* bmx) {
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = std::min(mn[a], bmn[a]);
+      mx[a] = std::max(mx[a], bmx[a]);
+    }
+  }
+  float half_area() const {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (!(dx >= 0.0f) || !(dy >= 0.0f) || !(dz >= 0.0f)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Child {
+  uint32_t ref;
+  Box box;
+  uint32_t height;
+};
+
+uint32_t ceil_log2(size_t n) {
+  uint32_t l = 0;
+  size_t v = 1;
+  while (v < n) { v <<= 1; ++l; }
+  return l;
+}
+
+struct Builder {
+  std::vector<BuildPrim>& prims;
+  std::vector<HostNode>& nodes;
+
+  float centroid(const BuildPrim& p, int axis) const { return 0.5f * (p.mn[axis] + p.mx[axis]); }
+
+  Child build(size_t lo, size_t hi, uint32_t budget) {
+    if (hi - lo == 1) {
+      Child c;
+      c.ref = prims[lo].ref;
+      c.box.reset();
+      c.box.grow(prims[lo].mn, prims[lo].mx);
+      c.height = 0;
+      return c;
+    }
+    const size_t n = hi - lo;
+    const uint32_t node_index = (uint32_t)nodes.size();
+    nodes.emplace_back();
+
+    Box cb;  // centroid bounds
+    cb.reset();
+    for (size_t i = lo; i < hi; ++i) {
+      const float c[3] = {centroid(prims[i], 0), centroid(prims[i], 1), centroid(prims[i], 2)};
+      cb.grow(c, c);
+    }
+    size_t mid = lo + n / 2;
+    const bool force_median = ceil_log2(n) + 1 >= budget;
+    bool split_done = false;
+    if (!force_median && n > 2) {
+      // binned SAH over the three axes
+      float best_cost = std::numeric_limits<float>::infinity();
+      int best_axis = -1, best_bin = -1;
+      for (int axis = 0; axis < 3; ++axis) {
+        const float extent = cb.mx[axis] - cb.mn[axis];
+        if (!(extent > 0.0f)) continue;
+        Box bin_box[kBins];
+        size_t bin_n[kBins];
+        for (int b = 0; b < kBins; ++b) { bin_box[b].reset(); bin_n[b] = 0; }
+        const float scale = (float)kBins / extent;
+        for (size_t i = lo; i < hi; ++i) {
+          int b = (int)((centroid(prims[i], axis) - cb.mn[axis]) * scale);
+          b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+          bin_box[b].grow(prims[i].mn, prims[i].mx);
+          ++bin_n[b];
+        }
+        float right_area[kBins];
+        size_t right_n[kBins];
+        Box acc;
+        acc.reset();
+        size_t cnt = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+          if (bin_n[b]) acc.grow(bin_box[b].mn, bin_box[b].mx);
+          cnt += bin_n[b];
+          right_area[b] = acc.half_area();
+          right_n[b] = cnt;
+        }
+        acc.reset();
+        cnt = 0;
+        for (int b = 0; b < kBins - 1; ++b) {
+          if (bin_n[b]) acc.grow(bin_box[b].mn, bin_box[b].mx);
+          cnt += bin_n[b];
+          if (cnt == 0 || right_n[b + 1] == 0) continue;
+          const float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_n[b + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        }
+      }
+      if (best_axis >= 0) {
+        const float extent = cb.mx[best_axis] - cb.mn[best_axis];
+        const float scale = (float)kBins / extent;
+        const float base = cb.mn[best_axis];
+        auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [&](const BuildPrim& p) {
+          int b = (int)((0.5f * (p.mn[best_axis] + p.mx[best_axis]) - base) * scale);
+          b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+          return b <= best_bin;
+        });
+        mid = (size_t)(it - prims.begin());
+        split_done = mid > lo && mid < hi;
+      }
+    }
+    if (!split_done) {
+      // balanced split along the widest centroid axis
+      int axis = 0;
+      float widest = -1.0f;
+      for (int a = 0; a < 3; ++a) {
+        const float e = cb.mx[a] - cb.mn[a];
+        if (e > widest) { widest = e; axis = a; }
+      }
+      mid = lo + n / 2;
+      std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
+                       [&](const BuildPrim& a, const BuildPrim& b) { return centroid(a, axis) < centroid(b, axis); });
+    }
+    const Child l = build(lo, mid, budget - 1);
+    const Child r = build(mid, hi, budget - 1);
+    HostNode& nd = nodes[node_index];
+    for (int a = 0; a < 3; ++a) {
+      nd.lmin[a] = l.box.mn[a]; nd.lmax[a] = l.box.mx[a];
+      nd.rmin[a] = r.box.mn[a]; nd.rmax[a] = r.box.mx[a];
+    }
+    nd.left = l.ref;
+    nd.right = r.ref;
+    nd.pad0 = 0;
+    nd.pad1 = 0;
+    Child c;
+    c.ref = node_index;
+    c.box = l.box;
+    c.box.grow(r.box.mn, r.box.mx);
+    c.height = 1 + std::max(l.height, r.height);
+    return c;
+  }
+};
+
+}  // namespace
+
+BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height) {
+  BuiltBvh out;
+  if (prims.empty()) return out;
+  out.nodes.reserve(prims.size());
+  Builder b{prims, out.nodes};
+  const Child root = b.build(0, prims.size(), max_height + 1);
+  out.root_ref = root.ref;
+  out.height = root.height;
+  for (int a = 0; a < 3; ++a) { out.mn[a] = root.box.mn[a]; out.mx[a] = root.box.mx[a]; }
+  return out;
+}
+
+}  // namespace mirt

@@ -1,0 +1,1041 @@
+// gfx950 kernels of the wavefront path tracer.
+//
+//   extend  : starts new camera paths in the free tail of the path buffer
+//             (renderer.rs:215-218, camera.rs:57-68), finds the closest hit of
+//             every path's current segment (world.rs:75-94 / bvh.rs:148-152)
+//             and bins the path by the material it hit
+//   shade   : one lane per binned path, material by material: rebuilds the hit
+//             record, evaluates emit / scatter / pdfs (renderer.rs:150-189),
+//             adds finished paths into the image sums and compacts the
+//             survivors into the other path buffer
+//   resolve : renderer.rs:232-259
+//   trace   : closest hit of caller-supplied rays
+//
+// Built with -ffp-contract=off: the intersection arithmetic has to round
+// exactly like the scalar f32 code of the reference.  Where a fused multiply
+// add is harmless (the conservative box test) it is written explicitly.
+#include <hip/hip_runtime.h>
+
+#include "scene_device.h"
+
+namespace mirt {
+
+namespace {
+
+constexpr float kInf = __builtin_huge_valf();
+constexpr float kPi = 3.14159265358979323846264338327950288f;
+constexpr float kTMin = 0.001f;  // renderer.rs:150
+
+// Boxes are grown by kBoxPad times the largest |coordinate| of the box
+// relative to the ray origin before the slab test.  The f32 sphere test of
+// the reference (objects.rs:42-56) reports hits for rays that miss the exact
+// sphere by up to ~sqrt(12*eps)*|origin-center| because of cancellation in
+// |os|^2 - r^2 and half_b^2 - a*c; the reference itself never culls
+// (aabb.rs:41-51 is always true on this path), so a box test that rejected
+// such a ray would change the result.  2^-8 leaves a 2.6x margin over that
+// bound with |origin-center| <= sqrt(3) * the max-norm distance used here.
+constexpr float kBoxPad = 0.00390625f;
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vec3.rs:119-121
+__device__ __forceinline__ float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }       // vec3.rs:94-96
+__device__ __forceinline__ float len(V3 a) { return sqrtf(len2(a)); }
+__device__ __forceinline__ V3 unit(V3 a) {  // vec3.rs:103-106
+  const float l = len(a);
+  return v3(a.x / l, a.y / l, a.z / l);
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {  // vec3.rs:123-129
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 xyz(float4 f) { return v3(f.x, f.y, f.z); }
+
+struct Ray {
+  V3 o, d;
+  float time;
+};
+__device__ __forceinline__ V3 ray_at(const Ray& r, float t) { return r.o + r.d * t; }  // ray.rs:19-21
+
+// ---- Philox4x32-10, keyed (pixel, sample, bounce*4+stage, block) ------------------
+constexpr uint32_t STAGE_CAMERA = 0, STAGE_MEDIA = 1, STAGE_SHADE = 2;
+
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+struct Rng {
+  uint32_t c0, c1, c2, k0, k1;
+  uint32_t next;
+  uint32_t block;
+  uint4 v;
+};
+__device__ __forceinline__ Rng rng_begin(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage,
+                                         uint32_t k0, uint32_t k1) {
+  Rng r;
+  r.c0 = pixel; r.c1 = sample; r.c2 = bounce * 4u + stage; r.k0 = k0; r.k1 = k1;
+  r.next = 0; r.block = 0xFFFFFFFFu; r.v = make_uint4(0, 0, 0, 0);
+  return r;
+}
+__device__ __forceinline__ float rng_at(Rng& r, uint32_t index) {  // uniform in [0,1), 24 bits
+  const uint32_t b = index >> 2;
+  if (b != r.block) {
+    r.v = philox4x32_10(r.c0, r.c1, r.c2, b, r.k0, r.k1);
+    r.block = b;
+  }
+  const uint32_t l = index & 3u;
+  const uint32_t x = l == 0 ? r.v.x : (l == 1 ? r.v.y : (l == 2 ? r.v.z : r.v.w));
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float rng_next(Rng& r) { return rng_at(r, r.next++); }
+__device__ __forceinline__ float rng_range(Rng& r, float lo, float hi) { return lo + (hi - lo) * rng_next(r); }
+
+__device__ __forceinline__ uint4 prim_info(const DeviceScene& sc, uint32_t ref) {
+  const uint32_t tag = ref_tag(ref);
+  const uint4* p = tag == TAG_SPHERE ? sc.info_sphere
+                   : tag == TAG_MOVING_SPHERE ? sc.info_msphere
+                   : tag == TAG_RECT ? sc.info_rect
+                                     : sc.info_box;
+  return p[ref_index(ref)];
+}
+__device__ __forceinline__ uint2 prim_ids(const DeviceScene& sc, uint32_t ref) {
+  const uint32_t tag = ref_tag(ref);
+  const uint2* p = tag == TAG_SPHERE ? sc.ids_sphere
+                   : tag == TAG_MOVING_SPHERE ? sc.ids_msphere
+                   : tag == TAG_RECT ? sc.ids_rect
+                                     : sc.ids_box;
+  return p[ref_index(ref)];
+}
+
+// ---- wrappers (transforms.rs) --------------------------------------------------
+// Applies the wrappers of a chain to a ray, outermost first (transforms.rs:16, 82-91).
+__device__ __forceinline__ Ray chain_forward(const DeviceScene& sc, uint32_t chain, Ray r) {
+  const uint2 c = sc.chains[chain];
+  for (uint32_t k = 0; k < c.y; ++k) {
+    const float4 op = sc.chain_ops[c.x + k];
+    const uint32_t kind = __float_as_uint(op.x);
+    if (kind == MIRT_OP_TRANSLATE) {
+      r.o = r.o - v3(op.y, op.z, op.w);
+    } else if (kind == MIRT_OP_ROTATE_Y) {
+      const float s = op.y, co = op.z;
+      const float ox = co * r.o.x - s * r.o.z;
+      const float oz = s * r.o.x + co * r.o.z;
+      const float dx = co * r.d.x - s * r.d.z;
+      const float dz = s * r.d.x + co * r.d.z;
+      r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+    }
+  }
+  return r;
+}
+
+// ---- primitive tests: t only (objects.rs) ---------------------------------------
+// All keep the comparisons of the reference (`root < t_min || root > t_max`)
+// except that a NaN root counts as a miss here.
+__device__ __forceinline__ bool in_range(float t, float t_min, float t_max) { return t >= t_min && t <= t_max; }
+
+__device__ __forceinline__ bool sphere_t(V3 center, float radius, const Ray& r, float t_min, float t_max, float& t) {
+  const V3 os = r.o - center;  // objects.rs:42-59
+  const float a = len2(r.d);
+  const float half_b = dot(os, r.d);
+  const float c = len2(os) - radius * radius;
+  const float disc = half_b * half_b - a * c;
+  if (disc < 0.0f) return false;
+  const float sq = sqrtf(disc);
+  float root = (-half_b - sq) / a;
+  if (!in_range(root, t_min, t_max)) {
+    root = (-half_b + sq) / a;
+    if (!in_range(root, t_min, t_max)) return false;
+  }
+  t = root;
+  return true;
+}
+
+__device__ __forceinline__ V3 moving_center(float4 m0, float4 m1, float4 m2, float time) {  // objects.rs:132-135
+  const V3 c0 = xyz(m0), c1 = xyz(m1);
+  const float time0 = m1.w, time1 = m2.x;
+  return c0 + ((time - time0) / (time1 - time0)) * (c1 - c0);
+}
+
+// Rect through plane `k` of axis n, spanning [a0,a1] x [b0,b1] on axes a, b.
+// axis 0: XY (n=z,a=x,b=y)  1: XZ (n=y,a=x,b=z)  2: YZ (n=x,a=y,b=z)   objects.rs:206-228,261-283,335-357
+__device__ __forceinline__ bool rect_core(float on, float dn, float oa, float da, float ob, float db, float a0,
+                                          float a1, float b0, float b1, float k, float t_min, float t_max, float& t,
+                                          float& pa, float& pb) {
+  const float tt = (k - on) / dn;
+  if (tt < t_min || tt > t_max) return false;
+  const float a = oa + tt * da;
+  const float b = ob + tt * db;
+  if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+  t = tt; pa = a; pb = b;
+  return true;
+}
+// (one call per axis: selecting ray components by a run-time axis makes the
+// compiler index a private-memory copy of the ray)
+__device__ __forceinline__ bool rect_t(uint32_t axis, float a0, float a1, float b0, float b1, float k, const Ray& r,
+                                       float t_min, float t_max, float& t, float& pa, float& pb) {
+  if (axis == 0) return rect_core(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, a0, a1, b0, b1, k, t_min, t_max, t, pa, pb);
+  if (axis == 1) return rect_core(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, a0, a1, b0, b1, k, t_min, t_max, t, pa, pb);
+  return rect_core(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, a0, a1, b0, b1, k, t_min, t_max, t, pa, pb);
+}
+
+// Box3d::hit: six rects in the reference's order with a shrinking t_max (objects.rs:396-436).
+// face: 0 xy@max.z, 1 xy@min.z, 2 xz@min.y, 3 xz@max.y, 4 yz@min.x, 5 yz@max.x
+__device__ __forceinline__ bool box_t(V3 mn, V3 mx, const Ray& r, float t_min, float t_max, float& t, int& face,
+                                      float& pa, float& pb) {
+  bool any = false;
+  float closest = t_max;
+  float tt, a, b;
+  if (rect_t(0, mn.x, mx.x, mn.y, mx.y, mx.z, r, t_min, closest, tt, a, b) && !(tt != tt)) { any = true; closest = tt; face = 0; pa = a; pb = b; }
+  if (rect_t(0, mn.x, mx.x, mn.y, mx.y, mn.z, r, t_min, closest, tt, a, b) && !(tt != tt)) { any = true; closest = tt; face = 1; pa = a; pb = b; }
+  if (rect_t(1, mn.x, mx.x, mn.z, mx.z, mn.y, r, t_min, closest, tt, a, b) && !(tt != tt)) { any = true; closest = tt; face = 2; pa = a; pb = b; }
+  if (rect_t(1, mn.x, mx.x, mn.z, mx.z, mx.y, r, t_min, closest, tt, a, b) && !(tt != tt)) { any = true; closest = tt; face = 3; pa = a; pb = b; }
+  if (rect_t(2, mn.y, mx.y, mn.z, mx.z, mn.x, r, t_min, closest, tt, a, b) && !(tt != tt)) { any = true; closest = tt; face = 4; pa = a; pb = b; }
+  if (rect_t(2, mn.y, mx.y, mn.z, mx.z, mx.x, r, t_min, closest, tt, a, b) && !(tt != tt)) { any = true; closest = tt; face = 5; pa = a; pb = b; }
+  t = closest;
+  return any;
+}
+
+// t of primitive `ref` for ray r (already in the primitive's object space).
+__device__ __forceinline__ bool prim_t_local(const DeviceScene& sc, uint32_t ref, const Ray& r, float t_min,
+                                             float t_max, float& t) {
+  const uint32_t tag = ref_tag(ref), idx = ref_index(ref);
+  if (tag == TAG_SPHERE) {
+    const float4 g = sc.sphere[idx];
+    return sphere_t(xyz(g), g.w, r, t_min, t_max, t);
+  } else if (tag == TAG_MOVING_SPHERE) {
+    const float4 m0 = sc.msphere[3 * idx], m1 = sc.msphere[3 * idx + 1], m2 = sc.msphere[3 * idx + 2];
+    return sphere_t(moving_center(m0, m1, m2, r.time), m0.w, r, t_min, t_max, t);
+  } else if (tag == TAG_RECT) {
+    const float4 g0 = sc.rect[2 * idx], g1 = sc.rect[2 * idx + 1];
+    float pa, pb;
+    const bool ok = rect_t(__float_as_uint(g1.y), g0.x, g0.y, g0.z, g0.w, g1.x, r, t_min, t_max, t, pa, pb);
+    return ok && !(t != t);
+  } else {
+    const float4 g0 = sc.box[2 * idx], g1 = sc.box[2 * idx + 1];
+    int face;
+    float pa, pb;
+    return box_t(xyz(g0), xyz(g1), r, t_min, t_max, t, face, pa, pb);
+  }
+}
+
+// Same with the primitive's wrappers applied to the world-space ray first.
+__device__ __forceinline__ bool prim_t(const DeviceScene& sc, uint32_t ref, const Ray& r, float t_min, float t_max,
+                                       float& t) {
+  if (sc.n_chains > 1) {
+    const uint32_t chain = prim_info(sc, ref).y;
+    if (chain != 0) {
+      const Ray lr = chain_forward(sc, chain, r);
+      return prim_t_local(sc, ref, lr, t_min, t_max, t);
+    }
+  }
+  return prim_t_local(sc, ref, r, t_min, t_max, t);
+}
+
+// ---- conservative box test ------------------------------------------------------
+// Entry distance of the padded box, or miss.  inv = 1/d per component.
+__device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min, float t_max, float& t_near) {
+  const V3 lo = bmin - o, hi = bmax - o;
+  const float l = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))),
+                        fmaxf(fabsf(lo.z), fabsf(hi.z)));
+  const float pad = l * kBoxPad;
+  const float x0 = (lo.x - pad) * inv.x, x1 = (hi.x + pad) * inv.x;
+  const float y0 = (lo.y - pad) * inv.y, y1 = (hi.y + pad) * inv.y;
+  const float z0 = (lo.z - pad) * inv.z, z1 = (hi.z + pad) * inv.z;
+  // fminf/fmaxf drop a NaN operand (0 * inf on a slab face): the axis then does not constrain
+  const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
+  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
+  t_near = tn;
+  return tn <= tf;
+}
+
+struct Work {
+  uint32_t nodes, prims;
+};
+
+// Closest surface over (t_min, inf): the result of the reference's exhaustive
+// scan -- smallest t, and of equal t the primitive with the higher `order`.
+template <bool COUNT>
+__device__ __forceinline__ void closest_surface(const DeviceScene& sc, const Ray& r, float t_min, uint32_t* stack,
+                                                uint32_t& best_ref, float& best_t, Work& work) {
+  best_ref = REF_NONE;
+  best_t = kInf;
+  uint32_t cur = sc.root_ref;
+  if (cur == REF_NONE) return;
+  const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+  int sp = 0;
+  for (;;) {
+    if (cur & REF_LEAF) {
+      float t;
+      if (COUNT) ++work.prims;
+      if (prim_t(sc, cur, r, t_min, best_t, t)) {
+        bool take = t < best_t || best_ref == REF_NONE;
+        if (!take) {  // t == best_t: the later one in the reference's visiting order wins
+          const uint32_t o_new = prim_info(sc, cur).z;
+          const uint32_t o_old = prim_info(sc, best_ref).z;
+          take = o_new > o_old;
+        }
+        if (take) { best_t = t; best_ref = cur; }
+      }
+      if (sp == 0) break;
+      cur = stack[(--sp) * BLOCK_THREADS];
+      continue;
+    }
+    if (COUNT) ++work.nodes;
+    const float4* n = sc.nodes + 4 * (size_t)cur;
+    const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    float tl, tr;
+    const bool hl = slab(xyz(n0), xyz(n1), r.o, inv, t_min, best_t, tl);
+    const bool hr = slab(xyz(n2), xyz(n3), r.o, inv, t_min, best_t, tr);
+    const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
+    if (hl && hr) {
+      const bool left_first = tl <= tr;
+      stack[(sp++) * BLOCK_THREADS] = left_first ? right : left;
+      cur = left_first ? left : right;
+    } else if (hl) {
+      cur = left;
+    } else if (hr) {
+      cur = right;
+    } else {
+      if (sp == 0) break;
+      cur = stack[(--sp) * BLOCK_THREADS];
+    }
+  }
+}
+
+// Constant media after the closest surface is known (transforms.rs:134-180).
+// Medium m reads draw m of the STAGE_MEDIA stream, so the order media are
+// visited in does not matter; an accepted medium hit replaces the current
+// closest hit exactly as World::hit does with its shrinking t_max.
+__device__ __forceinline__ void closest_media(const DeviceScene& sc, const Ray& r, float t_min, Rng& rng,
+                                              uint32_t& best_ref, float& best_t) {
+  for (uint32_t m = 0; m < sc.n_media; ++m) {
+    const DMedium med = sc.media[m];
+    float h1, h2;
+    if (!prim_t(sc, med.boundary_ref, r, -kInf, kInf, h1)) continue;
+    if (!prim_t(sc, med.boundary_ref, r, h1 + 0.0001f, kInf, h2)) continue;
+    if (h1 < t_min) h1 = t_min;
+    if (h2 > best_t) h2 = best_t;
+    if (h1 >= h2) continue;
+    if (h1 < 0.0f) h1 = 0.0f;
+    const Ray mr = med.chain != 0 ? chain_forward(sc, med.chain, r) : r;
+    const float ray_length = len(mr.d);
+    const float dist_inside = (h2 - h1) * ray_length;
+    const float hit_distance = med.neg_inv_density * log2f(rng_at(rng, m));  // log2, as the reference
+    if (hit_distance > dist_inside) continue;
+    best_t = h1 + hit_distance / ray_length;
+    best_ref = make_leaf(TAG_MEDIUM, m);
+  }
+}
+
+// ---- full hit record (hittable.rs:8-42) ------------------------------------------
+struct Hit {
+  V3 p, n;
+  float t, u, v;
+  bool front;
+  uint32_t material_word;
+};
+
+__device__ __forceinline__ void set_face(Hit& h, const Ray& r, V3 outward) {  // hittable.rs:28-35
+  h.front = dot(r.d, outward) < 0.0f;
+  h.n = h.front ? outward : -outward;
+}
+
+__device__ __forceinline__ void sphere_uv(V3 p, float& u, float& v) {  // objects.rs:17-28
+  const float theta = acosf(-p.y);
+  const float phi = -atan2f(p.z, p.x) + kPi;
+  u = phi / (2.0f * kPi);
+  v = theta / kPi;
+}
+
+__device__ __forceinline__ void sphere_record(V3 center, float radius, const Ray& r, float t, Hit& h) {
+  h.t = t;
+  h.p = ray_at(r, t);
+  const V3 outward = (h.p - center) / radius;  // objects.rs:61-63
+  sphere_uv(outward, h.u, h.v);
+  set_face(h, r, outward);
+}
+
+__device__ __forceinline__ void rect_record(uint32_t axis, float a0, float a1, float b0, float b1, const Ray& r,
+                                            float t, float pa, float pb, Hit& h) {
+  h.t = t;
+  h.u = (pa - a0) / (a1 - a0);
+  h.v = (pb - b0) / (b1 - b0);
+  h.p = ray_at(r, t);
+  set_face(h, r, axis == 0 ? v3(0.0f, 0.0f, 1.0f) : (axis == 1 ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f)));
+}
+
+// Rebuilds the record of the hit that closest_surface / closest_media found
+// at (ref, t), passing it through the wrappers inside-out as the nested
+// Hittable::hit calls of the reference do.
+__device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, const Ray& world_ray, float t_found) {
+  Hit h;
+  const uint32_t tag = ref_tag(ref), idx = ref_index(ref);
+  uint32_t chain;
+  if (tag == TAG_MEDIUM) {
+    chain = sc.media[idx].chain;
+    h.material_word = sc.media[idx].material_word;
+  } else {
+    const uint4 info = prim_info(sc, ref);
+    chain = info.y;
+    h.material_word = info.x;
+  }
+  // directions seen by each wrapper (after it transformed the ray)
+  V3 dir_at[MIRT_MAX_CHAIN_OPS];
+  Ray r = world_ray;
+  uint2 c = make_uint2(0, 0);
+  if (chain != 0) {
+    c = sc.chains[chain];
+    for (uint32_t k = 0; k < c.y && k < MIRT_MAX_CHAIN_OPS; ++k) {
+      const float4 op = sc.chain_ops[c.x + k];
+      const uint32_t kind = __float_as_uint(op.x);
+      if (kind == MIRT_OP_TRANSLATE) {
+        r.o = r.o - v3(op.y, op.z, op.w);
+      } else if (kind == MIRT_OP_ROTATE_Y) {
+        const float s = op.y, co = op.z;
+        const float ox = co * r.o.x - s * r.o.z;
+        const float oz = s * r.o.x + co * r.o.z;
+        const float dx = co * r.d.x - s * r.d.z;
+        const float dz = s * r.d.x + co * r.d.z;
+        r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+      }
+      dir_at[k] = r.d;
+    }
+  }
+  if (tag == TAG_MEDIUM) {  // transforms.rs:160-172
+    h.t = t_found;
+    h.p = ray_at(r, t_found);
+    h.n = v3(1.0f, 0.0f, 0.0f);
+    h.u = 0.0f; h.v = 0.0f;
+    h.front = true;
+  } else if (tag == TAG_SPHERE) {
+    const float4 g = sc.sphere[idx];
+    sphere_record(xyz(g), g.w, r, t_found, h);
+  } else if (tag == TAG_MOVING_SPHERE) {
+    const float4 m0 = sc.msphere[3 * idx], m1 = sc.msphere[3 * idx + 1], m2 = sc.msphere[3 * idx + 2];
+    sphere_record(moving_center(m0, m1, m2, r.time), m0.w, r, t_found, h);
+  } else if (tag == TAG_RECT) {
+    const float4 g0 = sc.rect[2 * idx], g1 = sc.rect[2 * idx + 1];
+    const uint32_t axis = __float_as_uint(g1.y);
+    float t, pa = 0.0f, pb = 0.0f;
+    rect_t(axis, g0.x, g0.y, g0.z, g0.w, g1.x, r, kTMin, kInf, t, pa, pb);
+    rect_record(axis, g0.x, g0.y, g0.z, g0.w, r, t_found, pa, pb, h);
+  } else {
+    const float4 g0 = sc.box[2 * idx], g1 = sc.box[2 * idx + 1];
+    const V3 mn = xyz(g0), mx = xyz(g1);
+    float t, pa = 0.0f, pb = 0.0f;
+    int face = 0;
+    box_t(mn, mx, r, kTMin, kInf, t, face, pa, pb);
+    const uint32_t axis = (uint32_t)face >> 1;
+    const float a0 = axis == 2 ? mn.y : mn.x, a1 = axis == 2 ? mx.y : mx.x;
+    const float b0 = axis == 0 ? mn.y : mn.z, b1 = axis == 0 ? mx.y : mx.z;
+    rect_record(axis, a0, a1, b0, b1, r, t_found, pa, pb, h);
+  }
+  if (chain != 0) {
+    for (int k = (int)c.y - 1; k >= 0; --k) {
+      const float4 op = sc.chain_ops[c.x + k];
+      const uint32_t kind = __float_as_uint(op.x);
+      const V3 d = dir_at[k < MIRT_MAX_CHAIN_OPS ? k : 0];
+      if (kind == MIRT_OP_TRANSLATE) {  // transforms.rs:18-19
+        h.p = h.p + v3(op.y, op.z, op.w);
+        h.front = dot(d, h.n) < 0.0f;
+      } else if (kind == MIRT_OP_ROTATE_Y) {  // transforms.rs:94-105
+        const float s = op.y, co = op.z;
+        V3 p = h.p, n = h.n;
+        p.x = co * h.p.x + s * h.p.z;
+        p.z = -s * h.p.x + co * h.p.z;
+        n.x = co * h.n.x + s * h.n.z;
+        n.z = -s * h.n.x + co * h.n.z;
+        h.p = p;
+        h.front = dot(d, n) < 0.0f;  // object-space direction, world-space normal
+        h.n = h.front ? n : -n;
+      } else {  // transforms.rs:199-201
+        h.front = !h.front;
+      }
+    }
+  }
+  return h;
+}
+
+// ---- textures (texture.rs, perlin.rs) ----------------------------------------------
+__device__ __forceinline__ float perlin_noise(const DeviceScene& sc, uint32_t table, V3 p) {  // perlin.rs:26-48,75-93
+  const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+  const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  const int i = (int)fx, j = (int)fy, k = (int)fz;
+  const uint32_t* perm = sc.perlin_perm + 768 * (size_t)table;
+  const float4* vec = sc.perlin_vec + 256 * (size_t)table;
+  const float uu = u * u * (3.0f - 2.0f * u);
+  const float vv = v * v * (3.0f - 2.0f * v);
+  const float ww = w * w * (3.0f - 2.0f * w);
+  float accum = 0.0f;
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {
+        const uint32_t h = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+        const V3 c = xyz(vec[h]);
+        const V3 weight = v3(u - (float)di, v - (float)dj, w - (float)dk);
+        accum += ((float)di * uu + (1.0f - (float)di) * (1.0f - uu)) *
+                 ((float)dj * vv + (1.0f - (float)dj) * (1.0f - vv)) *
+                 ((float)dk * ww + (1.0f - (float)dk) * (1.0f - ww)) * dot(c, weight);
+      }
+  return accum;
+}
+
+__device__ __forceinline__ float perlin_turb2(const DeviceScene& sc, uint32_t table, V3 p) {  // perlin.rs:50-60, depth 2
+  float accum = 0.0f;
+  accum += 1.0f * perlin_noise(sc, table, p);
+  accum += 0.5f * perlin_noise(sc, table, p * 2.0f);
+  return fabsf(accum);
+}
+
+__device__ __forceinline__ uint32_t f32_to_u32_sat(float v) {  // Rust `as u32`
+  if (!(v == v) || v <= 0.0f) return 0;
+  if (v >= 4294967040.0f) return 0xFFFFFFFFu;
+  return (uint32_t)v;
+}
+
+__device__ __forceinline__ V3 texture_color(const DeviceScene& sc, uint32_t tex, float u, float v, V3 p) {
+  for (int depth = 0; depth < 8; ++depth) {
+    const DTexture t = sc.textures[tex];
+    if (t.kind == MIRT_TEX_SOLID) {
+      return v3(t.r, t.g, t.b);
+    } else if (t.kind == MIRT_TEX_CHECKER) {  // texture.rs:51-60
+      const float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
+      tex = sines < 0.0f ? t.odd : t.even;
+    } else if (t.kind == MIRT_TEX_NOISE) {  // texture.rs:76-82
+      const float s = 1.0f + sinf(t.scale * p.z + 10.0f * perlin_turb2(sc, t.index, p));
+      return v3(1.0f, 1.0f, 1.0f) * 0.5f * s;
+    } else {  // texture.rs:101-122
+      const DImage im = sc.images[t.index];
+      const float cu = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+      const float cv = 1.0f - (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
+      uint32_t i = f32_to_u32_sat(cu * (float)im.width);
+      uint32_t j = f32_to_u32_sat(cv * (float)im.height);
+      if (i >= im.width) i = im.width - 1;
+      if (j >= im.height) j = im.height - 1;
+      const uint8_t* px = sc.image_data + im.offset + ((size_t)j * im.width + i) * 3;
+      const float scale = 1.0f / 255.0f;
+      return v3(scale * (float)px[0], scale * (float)px[1], scale * (float)px[2]);
+    }
+  }
+  return v3(0.0f, 0.0f, 0.0f);
+}
+
+// ---- sampling helpers (vec3.rs, onb.rs, pdf.rs) ------------------------------------
+struct Onb {
+  V3 u, v, w;
+};
+__device__ __forceinline__ Onb onb_from_w(V3 n) {  // onb.rs:10-20
+  Onb o;
+  o.w = unit(n);
+  const V3 a = fabsf(o.w.x) > 0.9f ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+  o.v = unit(cross(o.w, a));
+  o.u = cross(o.w, o.v);
+  return o;
+}
+__device__ __forceinline__ V3 onb_local(const Onb& o, V3 a) { return a.x * o.u + a.y * o.v + a.z * o.w; }  // onb.rs:26-28
+
+__device__ __forceinline__ V3 random_cosine_direction(Rng& rng) {  // vec3.rs:62-74
+  const float r1 = rng_next(rng), r2 = rng_next(rng);
+  const float z = sqrtf(1.0f - r2);
+  const float phi = 2.0f * kPi * r1;
+  const float sr = sqrtf(r2);
+  return v3(cosf(phi) * sr, sinf(phi) * sr, z);
+}
+__device__ __forceinline__ V3 random_to_sphere(Rng& rng, float radius, float dist2) {  // vec3.rs:76-88
+  const float r1 = rng_next(rng), r2 = rng_next(rng);
+  const float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / dist2) - 1.0f);
+  const float phi = 2.0f * kPi * r1;
+  const float s = sqrtf(1.0f - z * z);
+  return v3(cosf(phi) * s, sinf(phi) * s, z);
+}
+__device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:44-51
+  for (;;) {
+    const float x = rng_range(rng, -1.0f, 1.0f);
+    const float y = rng_range(rng, -1.0f, 1.0f);
+    const float z = rng_range(rng, -1.0f, 1.0f);
+    const V3 p = v3(x, y, z);
+    if (len2(p) < 1.0f) return p;
+  }
+}
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.0f * dot(v, n)) * n; }  // vec3.rs:108-110
+__device__ __forceinline__ V3 refract(V3 v, V3 n, float ratio) {                          // vec3.rs:112-117
+  const float cos_theta = fminf(dot(-v, n), 1.0f);
+  const V3 perp = ratio * (v + cos_theta * n);
+  const V3 par = (-sqrtf(fabsf(1.0f - len2(perp)))) * n;
+  return perp + par;
+}
+
+// pdf_value / random of one light object (objects.rs:82-100, 292-309, hittable.rs:52-57)
+__device__ __forceinline__ float light_pdf_value(const DLight& l, V3 origin, V3 dir) {
+  if (l.kind == MIRT_LIGHT_XZ_RECT) {
+    const float x0 = l.p[0], x1 = l.p[1], z0 = l.p[2], z1 = l.p[3], k = l.p[4];
+    // XZRect::hit with (0.0001, inf); comparisons written as in the reference so NaN flows the same way
+    const float t = (k - origin.y) / dir.y;
+    if (t < 0.0001f || t > kInf) return 0.0f;
+    const float x = origin.x + t * dir.x;
+    const float z = origin.z + t * dir.z;
+    if (x < x0 || x > x1 || z < z0 || z > z1) return 0.0f;
+    const float area = (x1 - x0) * (z1 - z0);
+    const float dist = t * t * len2(dir);
+    // hit.normal is +-(0,1,0): |dot(dir, normal) / |dir||
+    const bool front = dir.y < 0.0f;
+    const float dn = front ? (dir.x * 0.0f + dir.y * 1.0f + dir.z * 0.0f) : (dir.x * -0.0f + dir.y * -1.0f + dir.z * -0.0f);
+    const float cosine = fabsf(dn / len(dir));
+    return dist / (cosine * area);
+  } else if (l.kind == MIRT_LIGHT_SPHERE) {
+    const V3 c = v3(l.p[0], l.p[1], l.p[2]);
+    const float radius = l.p[3];
+    // Sphere::hit(.., 0.001, inf).is_some() with the reference's comparisons
+    const V3 os = origin - c;
+    const float a = len2(dir);
+    const float half_b = dot(os, dir);
+    const float cc = len2(os) - radius * radius;
+    const float disc = half_b * half_b - a * cc;
+    if (disc < 0.0f) return 0.0f;
+    const float sq = sqrtf(disc);
+    float root = (-half_b - sq) / a;
+    if (root < 0.001f || root > kInf) {
+      root = (-half_b + sq) / a;
+      if (root < 0.001f || root > kInf) return 0.0f;
+    }
+    const float cos_theta_max = sqrtf(1.0f - radius * radius / len2(c - origin));
+    const float solid_angle = 2.0f * kPi * (1.0f - cos_theta_max);
+    return 1.0f / solid_angle;
+  }
+  return 0.0f;
+}
+__device__ __forceinline__ V3 light_random(const DLight& l, V3 origin, Rng& rng) {
+  if (l.kind == MIRT_LIGHT_XZ_RECT) {
+    const float rx = rng_range(rng, l.p[0], l.p[1]);
+    const float rz = rng_range(rng, l.p[2], l.p[3]);
+    return v3(rx, l.p[4], rz) - origin;
+  } else if (l.kind == MIRT_LIGHT_SPHERE) {
+    const V3 dir = v3(l.p[0], l.p[1], l.p[2]) - origin;
+    const Onb uvw = onb_from_w(dir);
+    return onb_local(uvw, random_to_sphere(rng, l.p[3], len2(dir)));
+  }
+  return v3(1.0f, 0.0f, 0.0f);
+}
+// HittablePdf over the `lights` argument (pdf.rs:56-67, world.rs:100-117)
+__device__ __forceinline__ float lights_pdf_value(const DeviceScene& sc, V3 origin, V3 dir) {
+  if (sc.lights_mode == MIRT_LIGHTS_OBJECT) return light_pdf_value(sc.lights[0], origin, dir);
+  const float weight = 1.0f / (float)sc.n_lights;
+  float sum = 0.0f;
+  for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf_value(sc.lights[i], origin, dir);
+  return sum;
+}
+__device__ __forceinline__ V3 lights_random(const DeviceScene& sc, V3 origin, Rng& rng) {
+  if (sc.lights_mode == MIRT_LIGHTS_OBJECT) return light_random(sc.lights[0], origin, rng);
+  uint32_t g = (uint32_t)(rng_next(rng) * (float)sc.n_light_groups);
+  if (g >= sc.n_light_groups) g = sc.n_light_groups - 1;
+  const uint2 grp = sc.light_groups[g];
+  uint32_t i = (uint32_t)(rng_next(rng) * (float)grp.y);
+  if (i >= grp.y) i = grp.y - 1;
+  return light_random(sc.lights[grp.x + i], origin, rng);
+}
+
+__device__ __forceinline__ float reflectance(float cosine, float ref_idx) {  // material.rs:105-108
+  float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+  r0 = r0 * r0;
+  const float m = 1.0f - cosine;
+  const float m2 = m * m;
+  return r0 + (1.0f - r0) * (m2 * m2 * m);
+}
+
+// ---- wave helpers ---------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// Reserves one slot per lane that passes `pred` with a single atomic per wave.
+__device__ __forceinline__ uint32_t wave_reserve(bool pred, uint32_t* counter) {
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0ull) return 0;
+  const uint32_t lane = lane_id();
+  const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ int queue_of(uint32_t material_word) {
+  const uint32_t kind = material_word >> 28;
+  return kind == MIRT_MAT_LAMBERTIAN ? QUEUE_LAMBERTIAN
+         : kind == MIRT_MAT_METAL    ? QUEUE_METAL
+         : kind == MIRT_MAT_DIELECTRIC ? QUEUE_DIELECTRIC
+                                       : QUEUE_TERMINATE;
+}
+
+// Pixel of path number `idx` within one sample pass: 8-row bands walked column
+// by column, so the 64 lanes of a wave cover an 8x8 pixel tile.
+__device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t height, uint32_t& x, uint32_t& y) {
+  const uint32_t band_size = width * 8u;
+  const uint32_t band = idx / band_size;
+  const uint32_t in_band = idx - band * band_size;
+  const uint32_t rows = min(8u, height - band * 8u);
+  x = in_band / rows;
+  y = band * 8u + (in_band - x * rows);
+}
+
+// ---- extend -----------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK_THREADS) void k_extend(DeviceScene sc, RenderConst rc, float4* __restrict__ cur,
+                                                          IterCounters* counters, int parity, WorkCounters* work_out,
+                                                          uint32_t* __restrict__ queues) {
+  __shared__ uint32_t stack_mem[STACK_DEPTH * BLOCK_THREADS];
+  uint32_t* stack = stack_mem + threadIdx.x;
+
+  IterCounters* c = counters + parity;
+  IterCounters* nx = counters + (parity ^ 1);
+  const uint32_t n_surv = c->n_cur;
+  const uint64_t issued = c->issued;
+  const uint64_t remaining = rc.total_paths - issued;
+  const uint32_t room = rc.pool - n_surv;
+  const uint32_t n_new = remaining < (uint64_t)room ? (uint32_t)remaining : room;
+  const uint32_t n_tot = n_surv + n_new;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    nx->n_cur = 0;
+    nx->queue_n[0] = 0; nx->queue_n[1] = 0; nx->queue_n[2] = 0; nx->queue_n[3] = 0;
+    nx->issued = issued + n_new;
+  }
+  Work work{0, 0};
+  uint32_t segments = 0;
+  const uint32_t stride = gridDim.x * BLOCK_THREADS;
+  const uint32_t pixels = rc.width * rc.height;
+  // every lane of a wave runs the same number of rounds so the ballots below see whole waves
+  const uint32_t rounds = (n_tot + stride - 1) / stride;
+  for (uint32_t round = 0; round < rounds; ++round) {
+    const uint32_t i = round * stride + blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    const bool active = i < n_tot;
+    Ray r;
+    uint32_t pixel = 0, sample = 0, bounce = 0;
+    if (active) {
+      if (i < n_surv) {
+        const float4 r0 = cur[4 * (size_t)i], r1 = cur[4 * (size_t)i + 1];
+        const float4 r2 = cur[4 * (size_t)i + 2], r3 = cur[4 * (size_t)i + 3];
+        r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
+        pixel = __float_as_uint(r2.w);
+        sample = __float_as_uint(r3.x);
+        bounce = __float_as_uint(r3.y);
+      } else {
+        // new camera path (renderer.rs:215-218, camera.rs:57-68)
+        const uint64_t g = issued + (uint64_t)(i - n_surv);
+        const uint32_t pass = (uint32_t)(g / pixels);
+        const uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
+        uint32_t x, y;
+        pixel_of(in_pass, rc.width, rc.height, x, y);
+        pixel = y * rc.width + x;
+        sample = rc.first_sample + pass;
+        bounce = 0;
+        Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, rc.key0, rc.key1);
+        const float u = ((float)x + rng_next(rng)) / (float)(rc.width - 1);
+        const float v = ((float)y + rng_next(rng)) / (float)(rc.height - 1);
+        V3 disk;
+        for (;;) {  // vec3.rs:53-60
+          const float dx = rng_range(rng, -1.0f, 1.0f);
+          const float dy = rng_range(rng, -1.0f, 1.0f);
+          disk = v3(dx, dy, 0.0f);
+          if (len2(disk) < 1.0f) break;
+        }
+        const mirt_camera& cam = rc.cam;
+        const V3 rd = rc.cam.lens_radius * disk;
+        const V3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]);
+        const V3 offset = cu * rd.x + cv * rd.y;
+        const V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
+        const V3 llc = v3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
+        const V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+        const V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+        r.d = llc + u * hor + v * ver - origin - offset;
+        r.o = origin + offset;
+        r.time = rng_range(rng, cam.time0, cam.time1);
+        cur[4 * (size_t)i] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
+        cur[4 * (size_t)i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
+      }
+    }
+    uint32_t ref = REF_NONE;
+    float t = kInf;
+    if (active) {
+      closest_surface<COUNT>(sc, r, kTMin, stack, ref, t, work);
+      if (sc.n_media != 0) {
+        Rng rng = rng_begin(pixel, sample, bounce, STAGE_MEDIA, rc.key0, rc.key1);
+        closest_media(sc, r, kTMin, rng, ref, t);
+      }
+      ++segments;
+      cur[4 * (size_t)i + 1] = make_float4(r.d.x, r.d.y, r.d.z, t);
+      cur[4 * (size_t)i + 3] =
+          make_float4(__uint_as_float(sample), __uint_as_float(bounce), __uint_as_float(ref), 0.0f);
+    }
+    // bin by material
+    int q = -1;
+    if (active) {
+      if (ref == REF_NONE) {
+        q = QUEUE_TERMINATE;
+      } else if (ref_tag(ref) == TAG_MEDIUM) {
+        q = queue_of(sc.media[ref_index(ref)].material_word);
+      } else {
+        q = queue_of(prim_info(sc, ref).x);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N_QUEUES; ++k) {
+      const bool mine = q == k;
+      const uint32_t slot = wave_reserve(mine, &c->queue_n[k]);
+      if (mine) queues[(size_t)k * rc.pool + slot] = i;
+    }
+  }
+  if (COUNT) {
+    // one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+      work.nodes += __shfl_down(work.nodes, off);
+      work.prims += __shfl_down(work.prims, off);
+      segments += __shfl_down(segments, off);
+    }
+    if (lane_id() == 0) {
+      atomicAdd(&work_out->nodes, (unsigned long long)work.nodes);
+      atomicAdd(&work_out->prims, (unsigned long long)work.prims);
+      atomicAdd(&work_out->segments, (unsigned long long)segments);
+    }
+  }
+}
+
+// ---- shade ------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderConst rc,
+                                                         const float4* __restrict__ cur, float4* __restrict__ next,
+                                                         IterCounters* counters, int parity,
+                                                         const uint32_t* __restrict__ queues,
+                                                         float* __restrict__ rgb_sum) {
+  IterCounters* c = counters + parity;
+  IterCounters* nx = counters + (parity ^ 1);
+  // the four queues laid end to end, each starting at a wave boundary so a wave shades one material
+  const uint32_t n0 = c->queue_n[0], n1 = c->queue_n[1], n2 = c->queue_n[2], n3 = c->queue_n[3];
+  const uint32_t p1 = (n0 + 63u) & ~63u;
+  const uint32_t p2 = p1 + ((n1 + 63u) & ~63u);
+  const uint32_t p3 = p2 + ((n2 + 63u) & ~63u);
+  const uint32_t total = p3 + n3;
+  const uint32_t stride = gridDim.x * BLOCK_THREADS;
+  const uint32_t rounds = (total + stride - 1) / stride;
+  for (uint32_t round = 0; round < rounds; ++round) {
+    const uint32_t j = round * stride + blockIdx.x * BLOCK_THREADS + threadIdx.x;
+    int q;
+    uint32_t k;
+    if (j < p1) { q = 0; k = j; }
+    else if (j < p2) { q = 1; k = j - p1; }
+    else if (j < p3) { q = 2; k = j - p2; }
+    else { q = 3; k = j - p3; }
+    const uint32_t qn = q == 0 ? n0 : (q == 1 ? n1 : (q == 2 ? n2 : n3));
+    const bool active = j < total && k < qn;
+
+    bool alive = false;
+    Ray nr;
+    V3 beta = v3(0.0f, 0.0f, 0.0f);
+    uint32_t pixel = 0, sample = 0, bounce = 0;
+    if (active) {
+      const uint32_t i = queues[(size_t)q * rc.pool + k];
+      const float4 r0 = cur[4 * (size_t)i], r1 = cur[4 * (size_t)i + 1];
+      const float4 r2 = cur[4 * (size_t)i + 2], r3 = cur[4 * (size_t)i + 3];
+      Ray r;
+      r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
+      const float t = r1.w;
+      beta = xyz(r2);
+      pixel = __float_as_uint(r2.w);
+      sample = __float_as_uint(r3.x);
+      bounce = __float_as_uint(r3.y);
+      const uint32_t ref = __float_as_uint(r3.z);
+
+      V3 term = v3(0.0f, 0.0f, 0.0f);  // radiance that ends the path
+      if (ref == REF_NONE) {
+        term = v3(rc.background[0], rc.background[1], rc.background[2]);  // renderer.rs:187-189
+      } else {
+        const Hit h = hit_record(sc, ref, r, t);
+        const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
+        Rng rng = rng_begin(pixel, sample, bounce, STAGE_SHADE, rc.key0, rc.key1);
+        if (m.kind == MIRT_MAT_LAMBERTIAN) {  // material.rs:39-58, renderer.rs:166-183
+          const V3 att = texture_color(sc, m.texture, h.u, h.v, h.p);
+          const Onb uvw = onb_from_w(h.n);
+          V3 dir;
+          float pdf;
+          if (sc.lights_mode != MIRT_LIGHTS_NONE) {
+            if (rng_next(rng) < 0.5f) dir = lights_random(sc, h.p, rng);  // pdf.rs:85-91
+            else dir = onb_local(uvw, random_cosine_direction(rng));
+            const float c1 = dot(unit(dir), uvw.w);  // pdf.rs:25-32
+            const float cos_pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
+            pdf = 0.5f * lights_pdf_value(sc, h.p, dir) + 0.5f * cos_pdf;  // pdf.rs:81-83
+          } else {
+            dir = onb_local(uvw, random_cosine_direction(rng));
+            const float c1 = dot(unit(dir), uvw.w);
+            pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
+          }
+          const float c2 = dot(h.n, unit(dir));  // material.rs:50-57
+          const float spdf = c2 < 0.0f ? 0.0f : c2 / kPi;
+          beta = ((beta * att) * spdf) / pdf;
+          nr.o = h.p; nr.d = dir; nr.time = r.time;
+          alive = true;
+        } else if (m.kind == MIRT_MAT_METAL) {  // material.rs:75-91
+          const V3 reflected = reflect(unit(r.d), h.n);
+          const V3 fuzz = m.param * random_in_unit_sphere(rng);
+          const V3 att = texture_color(sc, m.texture, h.u, h.v, h.p);
+          beta = beta * att;
+          nr.o = h.p; nr.d = reflected + fuzz; nr.time = r.time;
+          alive = true;
+        } else if (m.kind == MIRT_MAT_DIELECTRIC) {  // material.rs:111-137
+          const float ratio = h.front ? 1.0f / m.param : m.param;
+          const V3 ud = unit(r.d);
+          const float cos_theta = fminf(dot(-ud, h.n), 1.0f);
+          const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+          bool do_reflect = ratio * sin_theta > 1.0f;
+          if (!do_reflect) do_reflect = reflectance(cos_theta, ratio) > rng_next(rng);
+          nr.d = do_reflect ? reflect(ud, h.n) : refract(ud, h.n, ratio);
+          nr.o = h.p; nr.time = r.time;
+          alive = true;
+        } else if (m.kind == MIRT_MAT_DIFFUSE_LIGHT) {  // material.rs:151-158
+          if (h.front) term = texture_color(sc, m.texture, h.u, h.v, h.p);
+        }
+        // MIRT_MAT_ISOTROPIC: no scatter, no emission
+      }
+      // The child call at depth 0 returns black without tracing (renderer.rs:147-149).
+      if (alive && bounce + 1 >= rc.max_depth) alive = false;
+      if (!alive) {
+        // beta * term is the path's whole contribution; it is added even when
+        // term is zero if beta is NaN/inf so a poisoned sample blackens its
+        // pixel as in the reference (renderer.rs:241-252: NaN as u8 == 0)
+        const V3 cval = beta * term;
+        if (!(cval.x == 0.0f && cval.y == 0.0f && cval.z == 0.0f)) {
+          const uint32_t y = pixel / rc.width, x = pixel - y * rc.width;
+          float* dst = rgb_sum + ((size_t)(rc.height - 1 - y) * rc.width + x) * 3;
+          atomicAdd(dst, cval.x);
+          atomicAdd(dst + 1, cval.y);
+          atomicAdd(dst + 2, cval.z);
+        }
+      }
+    }
+    const uint32_t slot = wave_reserve(alive, &nx->n_cur);
+    if (alive) {
+      next[4 * (size_t)slot] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
+      next[4 * (size_t)slot + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.0f);
+      next[4 * (size_t)slot + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(pixel));
+      next[4 * (size_t)slot + 3] =
+          make_float4(__uint_as_float(sample), __uint_as_float(bounce + 1), __uint_as_float(REF_NONE), 0.0f);
+    }
+  }
+}
+
+// ---- resolve (renderer.rs:232-259) -------------------------------------------------
+__global__ void k_resolve(const float* __restrict__ rgb_sum, uint32_t n_values, uint32_t spp,
+                          uint8_t* __restrict__ rgb24) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_values) return;
+  float v = sqrtf(rgb_sum[i] / (float)spp);
+  v = v < 0.0f ? 0.0f : (v > 0.999f ? 0.999f : v);  // f32::clamp keeps NaN
+  v = 255.999f * v;
+  uint8_t out;
+  if (!(v == v) || v <= 0.0f) out = 0;  // `as u8`: NaN -> 0, saturating
+  else if (v >= 255.0f) out = 255;
+  else out = (uint8_t)v;
+  rgb24[i] = out;
+}
+
+// ---- trace: closest hit of caller-supplied rays ------------------------------------
+__global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const mirt_ray* __restrict__ rays, size_t n,
+                                                         uint32_t key0, uint32_t key1,
+                                                         uint32_t* __restrict__ type_index,
+                                                         uint32_t* __restrict__ object_index, float* __restrict__ t_out) {
+  __shared__ uint32_t stack_mem[STACK_DEPTH * BLOCK_THREADS];
+  uint32_t* stack = stack_mem + threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const mirt_ray in = rays[i];
+  Ray r;
+  r.o = v3(in.origin[0], in.origin[1], in.origin[2]);
+  r.d = v3(in.direction[0], in.direction[1], in.direction[2]);
+  r.time = in.time;
+  uint32_t ref;
+  float t;
+  Work work{0, 0};
+  closest_surface<false>(sc, r, kTMin, stack, ref, t, work);
+  if (sc.n_media != 0) {
+    Rng rng = rng_begin((uint32_t)i, 0, 0, STAGE_MEDIA, key0, key1);
+    closest_media(sc, r, kTMin, rng, ref, t);
+  }
+  uint32_t ti = 0xFFFFFFFFu, oi = 0xFFFFFFFFu;
+  if (ref != REF_NONE) {
+    if (ref_tag(ref) == TAG_MEDIUM) {
+      ti = sc.media[ref_index(ref)].type_index;
+      oi = sc.media[ref_index(ref)].object_index;
+    } else {
+      const uint2 id = prim_ids(sc, ref);
+      ti = id.x; oi = id.y;
+    }
+  }
+  type_index[i] = ti;
+  object_index[i] = oi;
+  t_out[i] = ref != REF_NONE ? t : kInf;
+}
+
+}  // namespace
+
+// ---- launchers ------------------------------------------------------------------------
+void launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters, int parity,
+                   WorkCounters* work, uint32_t* queues, bool count_work, int grid, hipStream_t stream) {
+  if (count_work)
+    hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, sc, rc, cur, counters, parity, work,
+                       queues);
+  else
+    hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, sc, rc, cur, counters, parity,
+                       work, queues);
+}
+
+void launch_shade(const DeviceScene& sc, const RenderConst& rc, const float4* cur, float4* next,
+                  IterCounters* counters, int parity, const uint32_t* queues, float* rgb_sum, int grid,
+                  hipStream_t stream) {
+  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(BLOCK_THREADS), 0, stream, sc, rc, cur, next, counters, parity, queues,
+                     rgb_sum);
+}
+
+void launch_resolve(const float* rgb_sum, uint32_t n_values, uint32_t spp, uint8_t* rgb24, hipStream_t stream) {
+  const uint32_t block = 256;
+  hipLaunchKernelGGL(k_resolve, dim3((n_values + block - 1) / block), dim3(block), 0, stream, rgb_sum, n_values, spp,
+                     rgb24);
+}
+
+void launch_trace(const DeviceScene& sc, const mirt_ray* rays, size_t n, uint32_t key0, uint32_t key1,
+                  uint32_t* type_index, uint32_t* object_index, float* t, hipStream_t stream) {
+  if (n == 0) return;
+  const size_t grid = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
+  hipLaunchKernelGGL(k_trace, dim3((uint32_t)grid), dim3(BLOCK_THREADS), 0, stream, sc, rays, n, key0, key1,
+                     type_index, object_index, t);
+}
+
+int extend_blocks_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false>, BLOCK_THREADS, 0) != hipSuccess || n < 1) n = 4;
+  return n > 8 ? 8 : n;
+}
+int shade_blocks_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, BLOCK_THREADS, 0) != hipSuccess || n < 1) n = 4;
+  return n > 8 ? 8 : n;
+}
+
+}  // namespace mirt

@@ -1,0 +1,719 @@
+// C ABI of the MI355X path-tracing backend (include/mirt.h): context, scene
+// upload (lowered arrays -> device buffers + BVH) and the host loop that
+// drives the extend/shade kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mirt.h"
+#include "bvh_build.h"
+#include "scene_device.h"
+
+using namespace mirt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes && ptr) return hipSuccess;
+    release();
+    if (n == 0) n = 16;
+    const hipError_t e = hipMalloc(&ptr, n);
+    if (e == hipSuccess) bytes = n;
+    else ptr = nullptr;
+    return e;
+  }
+  template <class T>
+  T* as() const { return static_cast<T*>(ptr); }
+};
+
+}  // namespace
+
+struct mirt_context {
+  int device = 0;
+  int num_cu = 0;
+  std::string error;
+  hipStream_t stream = nullptr;  // used when the caller passes no stream
+  // render workspace, grown on demand and kept between calls
+  DeviceBuffer paths[2];
+  DeviceBuffer queues;
+  DeviceBuffer counters;
+  DeviceBuffer work;
+  DeviceBuffer image_sum;
+  DeviceBuffer image_rgb;
+  int extend_blocks = 0;
+  int shade_blocks = 0;
+};
+
+struct mirt_scene {
+  DeviceBuffer nodes, sphere, msphere, rect, box;
+  DeviceBuffer prim_info[N_PRIM_TAGS], prim_ids[N_PRIM_TAGS];
+  DeviceBuffer chains, chain_ops, materials, textures, perlin_vec, perlin_perm, images, image_data, lights,
+      light_groups, media;
+  DeviceScene view{};
+  float time0 = 0.0f, time1 = 0.0f;
+  bool has_moving = false;
+  uint32_t bvh_height = 0;
+  size_t n_prims = 0;
+};
+
+namespace {
+
+int fail(mirt_context* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->error = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define MIRT_HIP(ctx, call)                                                                      \
+  do {                                                                                           \
+    const hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                        \
+      return fail((ctx), e_ == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_DEVICE,   \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                            \
+  } while (0)
+
+template <class T>
+hipError_t upload(DeviceBuffer& buf, const std::vector<T>& host) {
+  hipError_t e = buf.ensure(host.size() * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (!host.empty()) e = hipMemcpy(buf.ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+
+struct P3 {
+  float x, y, z;
+};
+
+// object space -> world space through a chain (innermost wrapper first)
+P3 chain_to_world(const mirt_scene_desc& d, uint32_t chain, P3 p) {
+  const mirt_chain& c = d.chains[chain];
+  for (int k = (int)c.n_ops - 1; k >= 0; --k) {
+    const mirt_chain_op& op = d.chain_ops[c.first_op + k];
+    if (op.kind == MIRT_OP_TRANSLATE) {
+      p.x += op.p[0]; p.y += op.p[1]; p.z += op.p[2];
+    } else if (op.kind == MIRT_OP_ROTATE_Y) {
+      const float s = op.p[0], co = op.p[1];
+      const float x = co * p.x + s * p.z;
+      const float z = -s * p.x + co * p.z;
+      p.x = x; p.z = z;
+    }
+  }
+  return p;
+}
+
+struct Bounds {
+  float mn[3], mx[3];
+  Bounds() {
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = std::numeric_limits<float>::infinity();
+      mx[a] = -std::numeric_limits<float>::infinity();
+    }
+  }
+  void add(P3 p, float r = 0.0f) {
+    const float v[3] = {p.x, p.y, p.z};
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = std::min(mn[a], v[a] - r);
+      mx[a] = std::max(mx[a], v[a] + r);
+    }
+  }
+  // room for the rounding of the wrapper transforms themselves
+  void pad() {
+    for (int a = 0; a < 3; ++a) {
+      const float m = std::max(std::fabs(mn[a]), std::fabs(mx[a]));
+      const float e = m * 1e-5f + 1e-6f;
+      mn[a] -= e;
+      mx[a] += e;
+    }
+  }
+  bool finite() const {
+    for (int a = 0; a < 3; ++a)
+      if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return false;
+    return true;
+  }
+};
+
+void add_corners(const mirt_scene_desc& d, uint32_t chain, const float mn[3], const float mx[3], Bounds& b) {
+  for (int i = 0; i < 8; ++i) {
+    const P3 p{(i & 1) ? mx[0] : mn[0], (i & 2) ? mx[1] : mn[1], (i & 4) ? mx[2] : mn[2]};
+    b.add(chain_to_world(d, chain, p));
+  }
+}
+
+bool check_header(const mirt_scene_desc& d, const mirt_prim_header& h, std::string& why) {
+  if (h.material >= d.n_materials) { why = "primitive material index out of range"; return false; }
+  if (h.chain >= d.n_chains) { why = "primitive chain index out of range"; return false; }
+  return true;
+}
+
+int validate_desc(const mirt_scene_desc& d, std::string& why) {
+  if (d.n_chains == 0 || !d.chains || d.chains[0].n_ops != 0) { why = "chains[0] must be the empty chain"; return MIRT_ERR_INVALID_ARGUMENT; }
+  for (uint32_t i = 0; i < d.n_chains; ++i) {
+    if (d.chains[i].n_ops > MIRT_MAX_CHAIN_OPS) { why = "chain longer than MIRT_MAX_CHAIN_OPS"; return MIRT_ERR_UNSUPPORTED; }
+    if ((uint64_t)d.chains[i].first_op + d.chains[i].n_ops > d.n_chain_ops) { why = "chain ops out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+    for (uint32_t k = 0; k < d.chains[i].n_ops; ++k)
+      if (d.chain_ops[d.chains[i].first_op + k].kind > MIRT_OP_FLIP_FACE) { why = "unknown chain op"; return MIRT_ERR_INVALID_ARGUMENT; }
+  }
+  if (d.n_media > MIRT_MAX_MEDIA) { why = "more than MIRT_MAX_MEDIA constant media"; return MIRT_ERR_UNSUPPORTED; }
+  if (d.n_spheres >= MAX_PRIMS_PER_TAG || d.n_moving_spheres >= MAX_PRIMS_PER_TAG || d.n_rects >= MAX_PRIMS_PER_TAG ||
+      d.n_boxes >= MAX_PRIMS_PER_TAG) { why = "too many primitives of one kind"; return MIRT_ERR_UNSUPPORTED; }
+  for (uint32_t i = 0; i < d.n_spheres; ++i) if (!check_header(d, d.spheres[i].h, why)) return MIRT_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < d.n_moving_spheres; ++i) if (!check_header(d, d.moving_spheres[i].h, why)) return MIRT_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < d.n_rects; ++i) {
+    if (!check_header(d, d.rects[i].h, why)) return MIRT_ERR_INVALID_ARGUMENT;
+    if (d.rects[i].axis > MIRT_RECT_YZ) { why = "rect axis out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+  }
+  for (uint32_t i = 0; i < d.n_boxes; ++i) if (!check_header(d, d.boxes[i].h, why)) return MIRT_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < d.n_materials; ++i) {
+    const mirt_material& m = d.materials[i];
+    if (m.kind > MIRT_MAT_ISOTROPIC) { why = "unknown material kind"; return MIRT_ERR_INVALID_ARGUMENT; }
+    if (m.kind != MIRT_MAT_DIELECTRIC && m.texture >= d.n_textures) { why = "material texture index out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+  }
+  for (uint32_t i = 0; i < d.n_textures; ++i) {
+    const mirt_texture& t = d.textures[i];
+    if (t.kind > MIRT_TEX_IMAGE) { why = "unknown texture kind"; return MIRT_ERR_INVALID_ARGUMENT; }
+    if (t.kind == MIRT_TEX_CHECKER && (t.odd >= d.n_textures || t.even >= d.n_textures)) { why = "checker texture index out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+    if (t.kind == MIRT_TEX_NOISE && t.index >= d.n_perlins) { why = "noise texture perlin index out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+    if (t.kind == MIRT_TEX_IMAGE) {
+      if (t.index >= d.n_images) { why = "image texture index out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+      const mirt_image& im = d.images[t.index];
+      if (!im.rgb8 || im.width == 0 || im.height == 0) { why = "empty image"; return MIRT_ERR_INVALID_ARGUMENT; }
+    }
+  }
+  for (uint32_t i = 0; i < d.n_media; ++i) {
+    const mirt_medium& m = d.media[i];
+    if (m.material >= d.n_materials || m.chain >= d.n_chains) { why = "medium index out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+    const uint32_t lim = m.boundary_tag == MIRT_PRIM_SPHERE          ? d.n_spheres
+                         : m.boundary_tag == MIRT_PRIM_MOVING_SPHERE ? d.n_moving_spheres
+                         : m.boundary_tag == MIRT_PRIM_RECT          ? d.n_rects
+                         : m.boundary_tag == MIRT_PRIM_BOX           ? d.n_boxes
+                                                                     : 0;
+    if (m.boundary_index >= lim) { why = "medium boundary out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+  }
+  if (d.lights_mode > MIRT_LIGHTS_WORLD) { why = "unknown lights_mode"; return MIRT_ERR_INVALID_ARGUMENT; }
+  if (d.lights_mode != MIRT_LIGHTS_NONE && d.n_lights == 0) { why = "lights_mode set but no lights"; return MIRT_ERR_INVALID_ARGUMENT; }
+  if (d.lights_mode == MIRT_LIGHTS_WORLD) {
+    if (d.n_light_groups == 0) { why = "a World of lights needs light groups"; return MIRT_ERR_INVALID_ARGUMENT; }
+    for (uint32_t g = 0; g < d.n_light_groups; ++g)
+      if (d.light_groups[g].n_lights == 0 || (uint64_t)d.light_groups[g].first_light + d.light_groups[g].n_lights > d.n_lights) { why = "light group out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
+  }
+  if (!(d.time0 <= d.time1)) { why = "time0 must be <= time1"; return MIRT_ERR_INVALID_ARGUMENT; }
+  return MIRT_OK;
+}
+
+uint4 info_of(const mirt_scene_desc& d, const mirt_prim_header& h) {
+  return make_uint4(make_material_word(d.materials[h.material].kind, h.material), h.chain, h.order, h.flags);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mirt_version(void) { return 100; }
+
+const char* mirt_last_error(const mirt_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int mirt_context_create(int device_id, mirt_context** out) {
+  if (!out) return fail(nullptr, MIRT_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(nullptr, MIRT_ERR_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (device_id < 0 || device_id >= count) return fail(nullptr, MIRT_ERR_INVALID_ARGUMENT, "device_id out of range");
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail(nullptr, MIRT_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_id);
+  if (e != hipSuccess) return fail(nullptr, MIRT_ERR_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  mirt_context* ctx = new (std::nothrow) mirt_context();
+  if (!ctx) return fail(nullptr, MIRT_ERR_OUT_OF_MEMORY, "out of host memory");
+  ctx->device = device_id;
+  ctx->num_cu = prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(nullptr, MIRT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  ctx->extend_blocks = extend_blocks_per_cu();
+  ctx->shade_blocks = shade_blocks_per_cu();
+  *out = ctx;
+  return MIRT_OK;
+}
+
+void mirt_context_destroy(mirt_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+void mirt_scene_destroy(mirt_context* ctx, mirt_scene* scene) {
+  if (ctx) (void)hipSetDevice(ctx->device);
+  delete scene;
+}
+
+int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene** out) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!desc || !out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  const mirt_scene_desc& d = *desc;
+  std::string why;
+  const int vr = validate_desc(d, why);
+  if (vr != MIRT_OK) return fail(ctx, vr, why);
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+
+  mirt_scene* sp = new (std::nothrow) mirt_scene();
+  if (!sp) return fail(ctx, MIRT_ERR_OUT_OF_MEMORY, "out of host memory");
+  struct Guard {
+    mirt_scene* s;
+    ~Guard() { delete s; }
+  } guard{sp};
+  mirt_scene& s = *sp;
+  s.time0 = d.time0;
+  s.time1 = d.time1;
+  s.has_moving = d.n_moving_spheres != 0;
+
+  // ---- geometry + bounds ------------------------------------------------------
+  std::vector<BuildPrim> build;
+  build.reserve((size_t)d.n_spheres + d.n_moving_spheres + d.n_rects + d.n_boxes);
+  auto push_prim = [&](Bounds& b, uint32_t tag, uint32_t index, uint32_t flags) -> bool {
+    b.pad();
+    if (!b.finite()) return false;
+    if (flags & MIRT_PRIM_FLAG_BOUNDARY) return true;
+    BuildPrim p;
+    for (int a = 0; a < 3; ++a) { p.mn[a] = b.mn[a]; p.mx[a] = b.mx[a]; }
+    p.ref = make_leaf(tag, index);
+    build.push_back(p);
+    return true;
+  };
+  std::vector<float4> geo;
+  std::vector<uint4> info;
+  std::vector<uint2> ids;
+
+  geo.resize(d.n_spheres); info.resize(d.n_spheres); ids.resize(d.n_spheres);
+  for (uint32_t i = 0; i < d.n_spheres; ++i) {
+    const mirt_sphere& p = d.spheres[i];
+    geo[i] = make_float4(p.center[0], p.center[1], p.center[2], p.radius);
+    info[i] = info_of(d, p.h);
+    ids[i] = make_uint2(p.h.type_index, p.h.object_index);
+    Bounds b;
+    b.add(chain_to_world(d, p.h.chain, P3{p.center[0], p.center[1], p.center[2]}), std::fabs(p.radius));
+    if (!push_prim(b, TAG_SPHERE, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sphere with non-finite bounds");
+  }
+  MIRT_HIP(ctx, upload(s.sphere, geo));
+  MIRT_HIP(ctx, upload(s.prim_info[TAG_SPHERE], info));
+  MIRT_HIP(ctx, upload(s.prim_ids[TAG_SPHERE], ids));
+
+  geo.assign((size_t)d.n_moving_spheres * 3, make_float4(0, 0, 0, 0));
+  info.resize(d.n_moving_spheres); ids.resize(d.n_moving_spheres);
+  for (uint32_t i = 0; i < d.n_moving_spheres; ++i) {
+    const mirt_moving_sphere& p = d.moving_spheres[i];
+    geo[3 * (size_t)i] = make_float4(p.center0[0], p.center0[1], p.center0[2], p.radius);
+    geo[3 * (size_t)i + 1] = make_float4(p.center1[0], p.center1[1], p.center1[2], p.time0);
+    geo[3 * (size_t)i + 2] = make_float4(p.time1, 0, 0, 0);
+    info[i] = info_of(d, p.h);
+    ids[i] = make_uint2(p.h.type_index, p.h.object_index);
+    Bounds b;
+    // the centre is linear in time (objects.rs:132-135): bound the two ends of the valid interval
+    for (int e = 0; e < 2; ++e) {
+      const float time = e == 0 ? d.time0 : d.time1;
+      const float f = (time - p.time0) / (p.time1 - p.time0);
+      const P3 c{p.center0[0] + f * (p.center1[0] - p.center0[0]), p.center0[1] + f * (p.center1[1] - p.center0[1]),
+                 p.center0[2] + f * (p.center1[2] - p.center0[2])};
+      b.add(chain_to_world(d, p.h.chain, c), std::fabs(p.radius));
+    }
+    if (!push_prim(b, TAG_MOVING_SPHERE, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "moving sphere with non-finite bounds");
+  }
+  MIRT_HIP(ctx, upload(s.msphere, geo));
+  MIRT_HIP(ctx, upload(s.prim_info[TAG_MOVING_SPHERE], info));
+  MIRT_HIP(ctx, upload(s.prim_ids[TAG_MOVING_SPHERE], ids));
+
+  geo.assign((size_t)d.n_rects * 2, make_float4(0, 0, 0, 0));
+  info.resize(d.n_rects); ids.resize(d.n_rects);
+  for (uint32_t i = 0; i < d.n_rects; ++i) {
+    const mirt_rect& p = d.rects[i];
+    geo[2 * (size_t)i] = make_float4(p.a0, p.a1, p.b0, p.b1);
+    float axis_bits;
+    std::memcpy(&axis_bits, &p.axis, 4);
+    geo[2 * (size_t)i + 1] = make_float4(p.k, axis_bits, 0, 0);
+    info[i] = info_of(d, p.h);
+    ids[i] = make_uint2(p.h.type_index, p.h.object_index);
+    float mn[3], mx[3];
+    if (p.axis == MIRT_RECT_XY) { mn[0] = p.a0; mx[0] = p.a1; mn[1] = p.b0; mx[1] = p.b1; mn[2] = mx[2] = p.k; }
+    else if (p.axis == MIRT_RECT_XZ) { mn[0] = p.a0; mx[0] = p.a1; mn[2] = p.b0; mx[2] = p.b1; mn[1] = mx[1] = p.k; }
+    else { mn[1] = p.a0; mx[1] = p.a1; mn[2] = p.b0; mx[2] = p.b1; mn[0] = mx[0] = p.k; }
+    Bounds b;
+    add_corners(d, p.h.chain, mn, mx, b);
+    if (!push_prim(b, TAG_RECT, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "rect with non-finite bounds");
+  }
+  MIRT_HIP(ctx, upload(s.rect, geo));
+  MIRT_HIP(ctx, upload(s.prim_info[TAG_RECT], info));
+  MIRT_HIP(ctx, upload(s.prim_ids[TAG_RECT], ids));
+
+  geo.assign((size_t)d.n_boxes * 2, make_float4(0, 0, 0, 0));
+  info.resize(d.n_boxes); ids.resize(d.n_boxes);
+  for (uint32_t i = 0; i < d.n_boxes; ++i) {
+    const mirt_box& p = d.boxes[i];
+    geo[2 * (size_t)i] = make_float4(p.min[0], p.min[1], p.min[2], 0);
+    geo[2 * (size_t)i + 1] = make_float4(p.max[0], p.max[1], p.max[2], 0);
+    info[i] = info_of(d, p.h);
+    ids[i] = make_uint2(p.h.type_index, p.h.object_index);
+    Bounds b;
+    add_corners(d, p.h.chain, p.min, p.max, b);
+    if (!push_prim(b, TAG_BOX, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "box with non-finite bounds");
+  }
+  MIRT_HIP(ctx, upload(s.box, geo));
+  MIRT_HIP(ctx, upload(s.prim_info[TAG_BOX], info));
+  MIRT_HIP(ctx, upload(s.prim_ids[TAG_BOX], ids));
+
+  // ---- acceleration structure ----------------------------------------------------
+  s.n_prims = build.size();
+  BuiltBvh bvh = build_bvh(build, STACK_DEPTH - 2);
+  if (bvh.height > (uint32_t)STACK_DEPTH - 1) return fail(ctx, MIRT_ERR_UNSUPPORTED, "BVH taller than the traversal stack");
+  s.bvh_height = bvh.height;
+  MIRT_HIP(ctx, upload(s.nodes, bvh.nodes));
+
+  // ---- wrappers, media, materials, textures, lights ------------------------------------
+  std::vector<uint2> chains(d.n_chains);
+  for (uint32_t i = 0; i < d.n_chains; ++i) chains[i] = make_uint2(d.chains[i].first_op, d.chains[i].n_ops);
+  std::vector<float4> ops(d.n_chain_ops);
+  for (uint32_t i = 0; i < d.n_chain_ops; ++i) {
+    float kind_bits;
+    std::memcpy(&kind_bits, &d.chain_ops[i].kind, 4);
+    ops[i] = make_float4(kind_bits, d.chain_ops[i].p[0], d.chain_ops[i].p[1], d.chain_ops[i].p[2]);
+  }
+  MIRT_HIP(ctx, upload(s.chains, chains));
+  MIRT_HIP(ctx, upload(s.chain_ops, ops));
+
+  std::vector<DMaterial> mats(d.n_materials);
+  for (uint32_t i = 0; i < d.n_materials; ++i) mats[i] = DMaterial{d.materials[i].kind, d.materials[i].texture, d.materials[i].param, 0};
+  MIRT_HIP(ctx, upload(s.materials, mats));
+
+  std::vector<DTexture> texs(d.n_textures);
+  for (uint32_t i = 0; i < d.n_textures; ++i) {
+    const mirt_texture& t = d.textures[i];
+    texs[i] = DTexture{t.kind, t.odd, t.even, t.index, t.rgb[0], t.rgb[1], t.rgb[2], t.scale};
+  }
+  MIRT_HIP(ctx, upload(s.textures, texs));
+
+  std::vector<float4> pvec((size_t)d.n_perlins * 256);
+  std::vector<uint32_t> pperm((size_t)d.n_perlins * 768);
+  for (uint32_t i = 0; i < d.n_perlins; ++i) {
+    const mirt_perlin& p = d.perlins[i];
+    for (int k = 0; k < 256; ++k) {
+      pvec[(size_t)i * 256 + k] = make_float4(p.random_vec[k][0], p.random_vec[k][1], p.random_vec[k][2], 0);
+      pperm[(size_t)i * 768 + k] = p.perm_x[k] & 255u;
+      pperm[(size_t)i * 768 + 256 + k] = p.perm_y[k] & 255u;
+      pperm[(size_t)i * 768 + 512 + k] = p.perm_z[k] & 255u;
+    }
+  }
+  MIRT_HIP(ctx, upload(s.perlin_vec, pvec));
+  MIRT_HIP(ctx, upload(s.perlin_perm, pperm));
+
+  std::vector<DImage> images(d.n_images);
+  std::vector<uint8_t> image_data;
+  for (uint32_t i = 0; i < d.n_images; ++i) {
+    const mirt_image& im = d.images[i];
+    const size_t bytes = (size_t)im.width * im.height * 3;
+    images[i] = DImage{(uint64_t)image_data.size(), im.width, im.height};
+    if (im.rgb8) image_data.insert(image_data.end(), im.rgb8, im.rgb8 + bytes);
+  }
+  MIRT_HIP(ctx, upload(s.images, images));
+  MIRT_HIP(ctx, upload(s.image_data, image_data));
+
+  std::vector<DLight> lights(d.n_lights);
+  for (uint32_t i = 0; i < d.n_lights; ++i) {
+    lights[i].kind = d.lights[i].kind;
+    for (int k = 0; k < 5; ++k) lights[i].p[k] = d.lights[i].p[k];
+    lights[i].pad[0] = lights[i].pad[1] = 0;
+  }
+  std::vector<uint2> groups(d.n_light_groups);
+  for (uint32_t i = 0; i < d.n_light_groups; ++i) groups[i] = make_uint2(d.light_groups[i].first_light, d.light_groups[i].n_lights);
+  MIRT_HIP(ctx, upload(s.lights, lights));
+  MIRT_HIP(ctx, upload(s.light_groups, groups));
+
+  DeviceScene& v = s.view;
+  v.nodes = s.nodes.as<float4>();
+  v.root_ref = bvh.root_ref;
+  v.n_chains = d.n_chains;
+  v.sphere = s.sphere.as<float4>();
+  v.msphere = s.msphere.as<float4>();
+  v.rect = s.rect.as<float4>();
+  v.box = s.box.as<float4>();
+  v.info_sphere = s.prim_info[TAG_SPHERE].as<uint4>();
+  v.info_msphere = s.prim_info[TAG_MOVING_SPHERE].as<uint4>();
+  v.info_rect = s.prim_info[TAG_RECT].as<uint4>();
+  v.info_box = s.prim_info[TAG_BOX].as<uint4>();
+  v.ids_sphere = s.prim_ids[TAG_SPHERE].as<uint2>();
+  v.ids_msphere = s.prim_ids[TAG_MOVING_SPHERE].as<uint2>();
+  v.ids_rect = s.prim_ids[TAG_RECT].as<uint2>();
+  v.ids_box = s.prim_ids[TAG_BOX].as<uint2>();
+  v.chains = s.chains.as<uint2>();
+  v.chain_ops = s.chain_ops.as<float4>();
+  v.n_media = d.n_media;
+  std::vector<DMedium> media(d.n_media);
+  for (uint32_t i = 0; i < d.n_media; ++i) {
+    const mirt_medium& m = d.media[i];
+    DMedium& dm = media[i];
+    dm.boundary_ref = make_leaf(m.boundary_tag, m.boundary_index);
+    dm.neg_inv_density = m.neg_inv_density;
+    dm.material_word = make_material_word(d.materials[m.material].kind, m.material);
+    dm.chain = m.chain;
+    dm.order = m.order;
+    dm.type_index = m.type_index;
+    dm.object_index = m.object_index;
+    dm.pad = 0;
+  }
+  MIRT_HIP(ctx, upload(s.media, media));
+  v.media = s.media.as<DMedium>();
+  v.materials = s.materials.as<DMaterial>();
+  v.textures = s.textures.as<DTexture>();
+  v.perlin_vec = s.perlin_vec.as<float4>();
+  v.perlin_perm = s.perlin_perm.as<uint32_t>();
+  v.images = s.images.as<DImage>();
+  v.image_data = s.image_data.as<uint8_t>();
+  v.lights_mode = d.lights_mode;
+  v.n_lights = d.n_lights;
+  v.n_light_groups = d.n_light_groups;
+  v.lights = s.lights.as<DLight>();
+  v.light_groups = s.light_groups.as<uint2>();
+
+  guard.s = nullptr;
+  *out = sp;
+  return MIRT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera, const mirt_render_params* params,
+                float* rgb_sum_device, hipStream_t stream, mirt_stats* stats) {
+  if (!scene || !camera || !params || !rgb_sum_device) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  const mirt_render_params& p = *params;
+  if (p.width < 2 || p.height < 2) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
+  if ((uint64_t)p.width * p.height >= (1ull << 31)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "image too large");
+  if (p.samples_per_pixel == 0) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be positive");
+  if (!(camera->time0 <= camera->time1)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera time0 must be <= time1");
+  if (scene->has_moving && (camera->time0 < scene->time0 || camera->time1 > scene->time1))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera shutter interval outside the scene's time range");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const uint64_t total = (uint64_t)p.width * p.height * p.samples_per_pixel;
+  if (stats) stats->samples = total;
+  if (p.max_depth == 0) return MIRT_OK;  // renderer.rs:147-149: every sample is black
+
+  uint32_t pool = p.path_pool ? p.path_pool : (1u << 21);
+  pool = std::max(pool, 64u * 1024u);
+  pool = (pool + 255u) & ~255u;
+  if ((uint64_t)pool > total) pool = (uint32_t)((total + 255u) & ~255ull);
+
+  MIRT_HIP(ctx, ctx->paths[0].ensure((size_t)pool * 64));
+  MIRT_HIP(ctx, ctx->paths[1].ensure((size_t)pool * 64));
+  MIRT_HIP(ctx, ctx->queues.ensure((size_t)pool * 4 * N_QUEUES));
+  MIRT_HIP(ctx, ctx->counters.ensure(2 * sizeof(IterCounters)));
+  MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
+  MIRT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 2 * sizeof(IterCounters), stream));
+  MIRT_HIP(ctx, hipMemsetAsync(ctx->work.ptr, 0, sizeof(WorkCounters), stream));
+
+  RenderConst rc{};
+  rc.cam = *camera;
+  rc.width = p.width;
+  rc.height = p.height;
+  rc.first_sample = p.first_sample;
+  rc.max_depth = p.max_depth;
+  rc.background[0] = p.background[0]; rc.background[1] = p.background[1]; rc.background[2] = p.background[2];
+  rc.key0 = (uint32_t)p.seed;
+  rc.key1 = (uint32_t)(p.seed >> 32);
+  rc.pool = pool;
+  rc.total_paths = total;
+
+  const bool count_work = (p.flags & MIRT_RENDER_COUNT_WORK) != 0;
+  const bool time_kernels = (p.flags & MIRT_RENDER_TIME_KERNELS) != 0;
+  const int extend_grid = std::max(1, std::min(ctx->num_cu * ctx->extend_blocks, (int)((pool + 255u) / 256u)));
+  const int shade_grid = std::max(1, std::min(ctx->num_cu * ctx->shade_blocks, (int)((pool + 255u) / 256u)));
+
+  std::vector<hipEvent_t> events;  // start/stop pairs: extend, shade, extend, shade, ...
+  struct EventGuard {
+    std::vector<hipEvent_t>& ev;
+    ~EventGuard() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+  } event_guard{events};
+  auto stamp = [&]() -> hipError_t {
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return r;
+    events.push_back(e);
+    return hipEventRecord(e, stream);
+  };
+
+  float4* cur = ctx->paths[0].as<float4>();
+  float4* next = ctx->paths[1].as<float4>();
+  IterCounters* counters = ctx->counters.as<IterCounters>();
+  uint32_t* queues = ctx->queues.as<uint32_t>();
+  int parity = 0;
+  uint32_t iterations = 0;
+  uint64_t issued_seen = 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  for (;;) {
+    const uint64_t remaining = total - issued_seen;
+    uint64_t burst = remaining ? (remaining + pool - 1) / pool : p.max_depth;
+    burst = std::max<uint64_t>(1, std::min<uint64_t>(burst, 256));
+    for (uint64_t b = 0; b < burst; ++b) {
+      if (time_kernels) MIRT_HIP(ctx, stamp());
+      launch_extend(scene->view, rc, cur, counters, parity, ctx->work.as<WorkCounters>(), queues, count_work,
+                    extend_grid, stream);
+      if (time_kernels) { MIRT_HIP(ctx, stamp()); MIRT_HIP(ctx, stamp()); }
+      launch_shade(scene->view, rc, cur, next, counters, parity, queues, rgb_sum_device, shade_grid, stream);
+      if (time_kernels) MIRT_HIP(ctx, stamp());
+      std::swap(cur, next);
+      parity ^= 1;
+      ++iterations;
+    }
+    MIRT_HIP(ctx, hipGetLastError());
+    IterCounters h{};
+    MIRT_HIP(ctx, hipMemcpyAsync(&h, counters + parity, sizeof(h), hipMemcpyDeviceToHost, stream));
+    MIRT_HIP(ctx, hipStreamSynchronize(stream));
+    issued_seen = h.issued;
+    if (issued_seen >= total && h.n_cur == 0) break;
+    if (iterations > 100000000u) return fail(ctx, MIRT_ERR_DEVICE, "render did not converge");
+  }
+  const auto t_end = std::chrono::steady_clock::now();
+  if (stats) {
+    stats->render_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+    stats->iterations = iterations;
+    stats->path_pool = pool;
+    if (count_work) {
+      WorkCounters w{};
+      MIRT_HIP(ctx, hipMemcpy(&w, ctx->work.ptr, sizeof(w), hipMemcpyDeviceToHost));
+      stats->segments = w.segments;
+      stats->nodes_visited = w.nodes;
+      stats->prims_tested = w.prims;
+    }
+    if (time_kernels) {
+      for (size_t i = 0; i + 3 < events.size(); i += 4) {
+        float ms = 0.0f;
+        MIRT_HIP(ctx, hipEventElapsedTime(&ms, events[i], events[i + 1]));
+        stats->kernel_ms[MIRT_KERNEL_EXTEND] += ms;
+        stats->kernel_launches[MIRT_KERNEL_EXTEND] += 1;
+        MIRT_HIP(ctx, hipEventElapsedTime(&ms, events[i + 2], events[i + 3]));
+        stats->kernel_ms[MIRT_KERNEL_SHADE] += ms;
+        stats->kernel_launches[MIRT_KERNEL_SHADE] += 1;
+      }
+    }
+  }
+  return MIRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mirt_render_accumulate(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
+                           const mirt_render_params* params, float* rgb_sum_device, void* stream, mirt_stats* stats) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  return render_impl(ctx, scene, camera, params, rgb_sum_device, stream ? (hipStream_t)stream : ctx->stream, stats);
+}
+
+int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width, uint32_t height,
+                 uint32_t samples_per_pixel, uint8_t* rgb24_device, void* stream) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!rgb_sum_device || !rgb24_device || width == 0 || height == 0 || samples_per_pixel == 0)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "bad resolve argument");
+  if ((uint64_t)width * height * 3 >= (1ull << 32)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "image too large");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  launch_resolve(rgb_sum_device, width * height * 3, samples_per_pixel, rgb24_device, s);
+  MIRT_HIP(ctx, hipGetLastError());
+  MIRT_HIP(ctx, hipStreamSynchronize(s));
+  return MIRT_OK;
+}
+
+int mirt_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
+                const mirt_render_params* params, uint8_t* rgb24_out, float* rgb_sum_out, mirt_stats* stats) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!params) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  if ((uint64_t)params->width * params->height >= (1ull << 30)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "image too large");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n_values = (size_t)params->width * params->height * 3;
+  MIRT_HIP(ctx, ctx->image_sum.ensure(n_values * sizeof(float)));
+  MIRT_HIP(ctx, ctx->image_rgb.ensure(n_values));
+  MIRT_HIP(ctx, hipMemsetAsync(ctx->image_sum.ptr, 0, n_values * sizeof(float), ctx->stream));
+  const int rc = render_impl(ctx, scene, camera, params, ctx->image_sum.as<float>(), ctx->stream, stats);
+  if (rc != MIRT_OK) return rc;
+  if (rgb24_out) {
+    launch_resolve(ctx->image_sum.as<float>(), (uint32_t)n_values, params->samples_per_pixel,
+                   ctx->image_rgb.as<uint8_t>(), ctx->stream);
+    MIRT_HIP(ctx, hipGetLastError());
+    MIRT_HIP(ctx, hipMemcpyAsync(rgb24_out, ctx->image_rgb.ptr, n_values, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (rgb_sum_out)
+    MIRT_HIP(ctx, hipMemcpyAsync(rgb_sum_out, ctx->image_sum.ptr, n_values * sizeof(float), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+  MIRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MIRT_OK;
+}
+
+int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays_device, size_t n, uint64_t seed,
+                      uint32_t* type_index_device, uint32_t* object_index_device, float* t_device, void* stream) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!scene || (n && (!rays_device || !type_index_device || !object_index_device || !t_device)))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n >= (1ull << 31) * BLOCK_THREADS) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "too many rays");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  launch_trace(scene->view, rays_device, n, (uint32_t)seed, (uint32_t)(seed >> 32), type_index_device,
+               object_index_device, t_device, s);
+  MIRT_HIP(ctx, hipGetLastError());
+  MIRT_HIP(ctx, hipStreamSynchronize(s));
+  return MIRT_OK;
+}
+
+int mirt_trace_primary(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,
+                       uint32_t* type_index, uint32_t* object_index, float* t) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!scene || (n && (!rays || !type_index || !object_index || !t)))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n == 0) return MIRT_OK;
+  if (scene->has_moving)
+    for (size_t i = 0; i < n; ++i)
+      if (!(rays[i].time >= scene->time0 && rays[i].time <= scene->time1))
+        return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "ray time outside the scene's time range");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceBuffer d_rays, d_ti, d_oi, d_t;
+  MIRT_HIP(ctx, d_rays.ensure(n * sizeof(mirt_ray)));
+  MIRT_HIP(ctx, d_ti.ensure(n * 4));
+  MIRT_HIP(ctx, d_oi.ensure(n * 4));
+  MIRT_HIP(ctx, d_t.ensure(n * 4));
+  MIRT_HIP(ctx, hipMemcpy(d_rays.ptr, rays, n * sizeof(mirt_ray), hipMemcpyHostToDevice));
+  const int rc = mirt_trace_device(ctx, scene, d_rays.as<mirt_ray>(), n, seed, d_ti.as<uint32_t>(), d_oi.as<uint32_t>(),
+                                   d_t.as<float>(), nullptr);
+  if (rc != MIRT_OK) return rc;
+  MIRT_HIP(ctx, hipMemcpy(type_index, d_ti.ptr, n * 4, hipMemcpyDeviceToHost));
+  MIRT_HIP(ctx, hipMemcpy(object_index, d_oi.ptr, n * 4, hipMemcpyDeviceToHost));
+  MIRT_HIP(ctx, hipMemcpy(t, d_t.ptr, n * 4, hipMemcpyDeviceToHost));
+  return MIRT_OK;
+}
+
+}  // extern "C"
