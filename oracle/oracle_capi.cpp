@@ -263,6 +263,27 @@ uint32_t oracle_scene_object_count(void* h) {
   return n;
 }
 
+// In-order leaves of the bvh.rs tree (left to right); returns the leaf count.
+static void collect_leaves(const BVH& b, const BVH::Child& c, std::vector<WorldIndex>& out) {
+  if (!c.is_node) { out.push_back(c.index); return; }
+  collect_leaves(b, b.nodes[c.node].left, out);
+  collect_leaves(b, b.nodes[c.node].right, out);
+}
+uint32_t oracle_scene_bvh_leaf_order(void* h, uint32_t* type_index, uint32_t* object_index, uint32_t cap) {
+  Scene* s = static_cast<Scene*>(h);
+  if (!s->bvh || s->bvh->nodes.empty()) return 0;
+  std::vector<WorldIndex> leaves;
+  BVH::Child root;
+  root.is_node = true;
+  root.node = s->bvh->nodes.size() - 1;
+  collect_leaves(*s->bvh, root, leaves);
+  for (size_t i = 0; i < leaves.size() && i < cap; ++i) {
+    type_index[i] = leaves[i].type_index;
+    object_index[i] = leaves[i].object_index;
+  }
+  return (uint32_t)leaves.size();
+}
+
 // Renders samples [first_sample, first_sample+spp) of every pixel.
 // rgb_sum (optional): W*H*3 f32 sums, row 0 = image top (the layout
 // renderer.rs:254-258 gives the RGB24 buffer).  rgb24 (optional): the encoded

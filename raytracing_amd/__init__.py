@@ -307,6 +307,12 @@ class ExampleScene:
         return ti, oi, t
 
 
+def shard_samples(spp, world_size, rank):
+    """Sample-range sharding: rank r renders samples [first, first + count) of every pixel."""
+    base, extra = divmod(spp, world_size)
+    return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
+
+
 def camera_rays(cam, width, height, time=0.5):
     """Pixel-centre rays of a mirt Camera, lens offset zero; ray i = y*W + x, y up (camera.rs:61-62 in f32)."""
     f = np.float32

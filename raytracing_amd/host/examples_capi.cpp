@@ -29,13 +29,14 @@ extern "C" {
 
 const char* rt_example_last_error(void) { return g_error.c_str(); }
 
+}  // extern "C"
+
 // name: spheres | spheres_bvh | cornel_box | final_scene | synthetic:<half> | synthetic_bvh:<half>
-void* rt_example_open(const char* name_c, uint64_t scene_seed, const char* asset_dir, int device) {
-  const std::string name = name_c ? name_c : "";
-  auto ex = std::make_unique<Example>();
-  ex->name = name;
+// Builds the scene with the host mirror and hands (hittable, lights) to `sink`.
+template <class Sink>
+static bool with_example(const std::string& name, uint64_t scene_seed, const char* asset_dir, Example& ex, Sink&& sink) {
+  ex.name = name;
   rt::seed(scene_seed);
-  rt::Status st;
   if (name == "spheres" || name == "spheres_bvh" || name.rfind("synthetic:", 0) == 0 ||
       name.rfind("synthetic_bvh:", 0) == 0) {
     int half = 11;
@@ -45,41 +46,102 @@ void* rt_example_open(const char* name_c, uint64_t scene_seed, const char* asset
       half = std::atoi(name.c_str() + name.find(':') + 1);
       inclusive = true;
       use_bvh = name.rfind("synthetic_bvh:", 0) == 0;
-      if (half < 1) { g_error = "bad synthetic size"; return nullptr; }
+      if (half < 1) { g_error = "bad synthetic size"; return false; }
     }
     rt::World world = rt::scenes::random_spheres(half, inclusive);
-    ex->top_level_objects = world.len();
-    ex->default_aspect = 16.0f / 9.0f;
-    ex->width = 600; ex->height = (uint32_t)(600.0f / ex->default_aspect); ex->spp = 10; ex->depth = 10;
-    ex->background = rt::Color(0.8f, 0.8f, 0.8f);
-    ex->weekend_camera = true;
+    ex.top_level_objects = world.len();
+    ex.default_aspect = 16.0f / 9.0f;
+    ex.width = 600; ex.height = (uint32_t)(600.0f / ex.default_aspect); ex.spp = 10; ex.depth = 10;
+    ex.background = rt::Color(0.8f, 0.8f, 0.8f);
+    ex.weekend_camera = true;
     if (use_bvh) {
       rt::BVH bvh = rt::BVH::from_world(std::move(world), 0.0f, 1.0f);
-      st = ex->device.build<rt::BVH, rt::BVH>(bvh, nullptr, 0.0f, 1.0f, device);
-    } else {
-      st = ex->device.build<rt::World, rt::World>(world, nullptr, 0.0f, 1.0f, device);
+      return sink(bvh, (const rt::BVH*)nullptr);
     }
-  } else if (name == "cornel_box") {
+    return sink(world, (const rt::World*)nullptr);
+  }
+  if (name == "cornel_box") {
     rt::World world = rt::scenes::cornell_box();
     rt::World lights = rt::scenes::cornell_lights();
-    ex->top_level_objects = world.len();
-    ex->default_aspect = 1.0f;
-    ex->width = 1000; ex->height = 1000; ex->spp = 5; ex->depth = 5;
-    st = ex->device.build(world, &lights, 0.0f, 1.0f, device);
-  } else if (name == "final_scene") {
-    auto world = rt::scenes::final_scene(std::string(asset_dir ? asset_dir : ".") + "/earthmap_1024x512.rgb");
-    if (!world.is_ok()) { g_error = world.error; return nullptr; }
-    auto light = rt::scenes::final_scene_light();
-    ex->top_level_objects = world.unwrap().len();
-    ex->default_aspect = 1.0f;
-    ex->width = 600; ex->height = 600; ex->spp = 5; ex->depth = 5;
-    st = ex->device.build(world.unwrap(), &light, 0.0f, 1.0f, device);
-  } else {
-    g_error = "unknown scene '" + name + "'";
-    return nullptr;
+    ex.top_level_objects = world.len();
+    ex.default_aspect = 1.0f;
+    ex.width = 1000; ex.height = 1000; ex.spp = 5; ex.depth = 5;
+    return sink(world, (const rt::World*)&lights);
   }
-  if (!st.is_ok()) { g_error = st.error; return nullptr; }
-  return ex.release();
+  if (name == "final_scene") {
+    auto world = rt::scenes::final_scene(std::string(asset_dir ? asset_dir : ".") + "/earthmap_1024x512.rgb");
+    if (!world.is_ok()) { g_error = world.error; return false; }
+    auto light = rt::scenes::final_scene_light();
+    ex.top_level_objects = world.unwrap().len();
+    ex.default_aspect = 1.0f;
+    ex.width = 600; ex.height = 600; ex.spp = 5; ex.depth = 5;
+    return sink(world.unwrap(), &light);
+  }
+  g_error = "unknown scene '" + name + "'";
+  return false;
+}
+
+// lowering only (no GPU): lets the host logic be checked on a CPU-only machine
+struct Lowered {
+  Example ex;
+  rt::Lowerer L;
+};
+
+extern "C" {
+
+void* rt_example_open(const char* name_c, uint64_t scene_seed, const char* asset_dir, int device) {
+  auto ex = std::make_unique<Example>();
+  Example& e = *ex;
+  const bool ok = with_example(name_c ? name_c : "", scene_seed, asset_dir, e, [&](const auto& hittable, const auto* lights) {
+    const rt::Status st = e.device.build(hittable, lights, 0.0f, 1.0f, device);
+    if (!st.is_ok()) g_error = st.error;
+    return st.is_ok();
+  });
+  return ok ? ex.release() : nullptr;
+}
+
+void* rt_lowered_open(const char* name_c, uint64_t scene_seed, const char* asset_dir) {
+  auto lo = std::make_unique<Lowered>();
+  Lowered& l = *lo;
+  const bool ok = with_example(name_c ? name_c : "", scene_seed, asset_dir, l.ex, [&](const auto& hittable, const auto* lights) {
+    rt::lower_root(hittable, l.L);
+    if (lights) lights->lower_lights_argument(l.L);
+    if (!l.L.error.empty()) { g_error = l.L.error; return false; }
+    return true;
+  });
+  return ok ? lo.release() : nullptr;
+}
+void rt_lowered_close(void* h) { delete static_cast<Lowered*>(h); }
+// out: spheres, moving spheres, rects, boxes, chains, chain ops, media, materials, textures, perlins, images,
+//      lights, light groups, lights_mode, top-level objects, 0
+void rt_lowered_counts(void* h, uint32_t out[16]) {
+  const rt::Lowerer& L = static_cast<Lowered*>(h)->L;
+  const uint32_t v[16] = {(uint32_t)L.spheres.size(), (uint32_t)L.moving_spheres.size(), (uint32_t)L.rects.size(),
+                          (uint32_t)L.boxes.size(), (uint32_t)L.chains.size(), (uint32_t)L.chain_ops.size(),
+                          (uint32_t)L.media.size(), (uint32_t)L.materials.size(), (uint32_t)L.textures.size(),
+                          (uint32_t)L.perlins.size(), (uint32_t)L.images.size(), (uint32_t)L.lights.size(),
+                          (uint32_t)L.light_groups.size(), L.lights_mode,
+                          (uint32_t)static_cast<Lowered*>(h)->ex.top_level_objects, 0};
+  std::memcpy(out, v, sizeof(v));
+}
+// Every surface primitive as rows of (tag, type_index, object_index, order, chain, material kind); returns the count.
+uint32_t rt_lowered_prims(void* h, uint32_t* rows, uint32_t cap) {
+  const rt::Lowerer& L = static_cast<Lowered*>(h)->L;
+  uint32_t n = 0;
+  auto put = [&](uint32_t tag, const mirt_prim_header& ph) {
+    if (ph.flags & MIRT_PRIM_FLAG_BOUNDARY) return;
+    if (n < cap) {
+      uint32_t* r = rows + 6 * (size_t)n;
+      r[0] = tag; r[1] = ph.type_index; r[2] = ph.object_index; r[3] = ph.order; r[4] = ph.chain;
+      r[5] = L.materials[ph.material].kind;
+    }
+    ++n;
+  };
+  for (const auto& p : L.spheres) put(MIRT_PRIM_SPHERE, p.h);
+  for (const auto& p : L.moving_spheres) put(MIRT_PRIM_MOVING_SPHERE, p.h);
+  for (const auto& p : L.rects) put(MIRT_PRIM_RECT, p.h);
+  for (const auto& p : L.boxes) put(MIRT_PRIM_BOX, p.h);
+  return n;
 }
 
 void rt_example_close(void* h) { delete static_cast<Example*>(h); }

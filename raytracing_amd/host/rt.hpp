@@ -179,7 +179,7 @@ struct Lowerer {
     h.order = visit_counter++;
     h.type_index = type_index;
     h.object_index = object_index;
-    h.flags = boundary_mode ? MIRT_PRIM_FLAG_BOUNDARY : 0u;
+    h.flags = boundary_mode ? (uint32_t)MIRT_PRIM_FLAG_BOUNDARY : 0u;
     return h;
   }
   void note_boundary(uint32_t tag, uint32_t index) {

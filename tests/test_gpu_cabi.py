@@ -1,0 +1,201 @@
+"""GPU tests that drive include/mirt.h directly with hand-built scene descriptions (edge cases and errors)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import raytracing_amd as R
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+class Ctx:
+    def __init__(self):
+        self.L = R.mirt()
+        self.ctx = C.c_void_p()
+        rc = self.L.mirt_context_create(0, C.byref(self.ctx))
+        assert rc == 0, self.L.mirt_last_error(None)
+        self.scenes = []
+
+    def close(self):
+        for s in self.scenes:
+            self.L.mirt_scene_destroy(self.ctx, s)
+        self.L.mirt_context_destroy(self.ctx)
+
+    def error(self):
+        return self.L.mirt_last_error(self.ctx).decode()
+
+    def upload(self, spheres=(), rects=(), boxes=(), moving=(), materials=None, textures=None, chains=None,
+               chain_ops=(), time=(0.0, 1.0), expect=0):
+        keep = []
+
+        def arr(T, items):
+            a = (T * max(1, len(items)))(*items)
+            keep.append(a)
+            return a
+        d = R.SceneDesc()
+        d.spheres, d.n_spheres = arr(R.Sphere, spheres), len(spheres)
+        d.moving_spheres, d.n_moving_spheres = arr(R.MovingSphere, moving), len(moving)
+        d.rects, d.n_rects = arr(R.Rect, rects), len(rects)
+        d.boxes, d.n_boxes = arr(R.Box, boxes), len(boxes)
+        chains = chains if chains is not None else [R.Chain(0, 0)]
+        d.chains, d.n_chains = arr(R.Chain, chains), len(chains)
+        d.chain_ops, d.n_chain_ops = arr(R.ChainOp, chain_ops), len(chain_ops)
+        materials = materials if materials is not None else [R.Material(0, 0, 0.0)]
+        textures = textures if textures is not None else [R.Texture(0, (C.c_float * 3)(0.5, 0.5, 0.5), 0, 0, 0.0, 0)]
+        d.materials, d.n_materials = arr(R.Material, materials), len(materials)
+        d.textures, d.n_textures = arr(R.Texture, textures), len(textures)
+        d.time0, d.time1 = time
+        scene = C.c_void_p()
+        rc = self.L.mirt_scene_upload(self.ctx, C.byref(d), C.byref(scene))
+        assert rc == expect, (rc, self.error())
+        if rc == 0:
+            self.scenes.append(scene)
+        return scene
+
+    def trace(self, scene, rays, expect=0):
+        rays = np.ascontiguousarray(rays, F).reshape(-1, 7)
+        n = len(rays)
+        ti, oi, t = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, F)
+        rc = self.L.mirt_trace_primary(self.ctx, scene, rays.ctypes.data, n, 0, ti.ctypes.data, oi.ctypes.data,
+                                       t.ctypes.data)
+        assert rc == expect, (rc, self.error())
+        return ti, oi, t
+
+    def render(self, scene, w, h, spp, depth=5, bg=(0.25, 0.5, 1.0), expect=0, cam=None):
+        cam = cam or simple_camera()
+        p = R.RenderParams(w, h, spp, 0, depth, (C.c_float * 3)(*bg), 9, 0, 0)
+        rgb = np.zeros((h, w, 3), np.uint8)
+        sums = np.zeros((h, w, 3), F)
+        st = R.Stats()
+        rc = self.L.mirt_render(self.ctx, scene, C.byref(cam), C.byref(p), rgb.ctypes.data, sums.ctypes.data,
+                                C.byref(st))
+        assert rc == expect, (rc, self.error())
+        return rgb, sums, st
+
+
+def simple_camera(time0=0.0, time1=1.0):
+    # looks down -z from the origin: lower-left corner (-1,-1,-1), 2x2 viewport
+    c = R.Camera()
+    c.origin[:] = [0, 0, 0]
+    c.lower_left_corner[:] = [-1, -1, -1]
+    c.horizontal[:] = [2, 0, 0]
+    c.vertical[:] = [0, 2, 0]
+    c.u[:] = [1, 0, 0]
+    c.v[:] = [0, 1, 0]
+    c.w[:] = [0, 0, 1]
+    c.lens_radius, c.time0, c.time1 = 0.0, time0, time1
+    return c
+
+
+def hdr(order, ti=0, oi=0, material=0, chain=0, flags=0):
+    return R.PrimHeader(material, chain, order, ti, oi, flags)
+
+
+def sphere(c, r, order, ti=0, oi=0, **kw):
+    return R.Sphere(hdr(order, ti, oi, **kw), (C.c_float * 3)(*c), r)
+
+
+@pytest.fixture()
+def ctx():
+    c = Ctx()
+    yield c
+    c.close()
+
+
+def test_empty_scene_renders_background_and_traces_misses(ctx):
+    scene = ctx.upload()
+    ti, oi, t = ctx.trace(scene, [[0, 0, 0, 0, 0, -1, 0.5]] * 3)
+    assert np.all(ti == 0xFFFFFFFF) and np.all(oi == 0xFFFFFFFF) and np.all(np.isinf(t))
+    rgb, sums, st = ctx.render(scene, 16, 8, 3)
+    assert np.allclose(sums, np.array([0.25, 0.5, 1.0], F) * 3)
+    assert np.array_equal(rgb, O.encode(sums, 3))
+
+
+def test_single_primitive_known_answer(ctx):
+    """objects.rs:42-59 by hand: unit sphere, ray from (0,0,-5) along +z hits at t = 4."""
+    scene = ctx.upload(spheres=[sphere((0, 0, 0), 1.0, 0, ti=3, oi=7)])
+    ti, oi, t = ctx.trace(scene, [[0, 0, -5, 0, 0, 1, 0], [0, 2, -5, 0, 0, 1, 0], [0, 0, -5, 0, 0, 2, 0],
+                                  [0, 0, 0, 1, 0, 0, 0]])
+    assert list(ti) == [3, 0xFFFFFFFF, 3, 3] and list(oi) == [7, 0xFFFFFFFF, 7, 7]
+    assert t[0] == 4.0 and np.isinf(t[1]) and t[2] == 2.0 and t[3] == 1.0
+
+
+def test_equal_t_goes_to_the_higher_order(ctx):
+    """Two identical spheres: world.rs:75-94 lets the later one replace an equal t; bvh.rs:122-126 the right leaf."""
+    for first_wins in (False, True):
+        a = sphere((0, 0, -3), 1.0, 5 if first_wins else 1, ti=0, oi=0)
+        b = sphere((0, 0, -3), 1.0, 2, ti=1, oi=0)
+        scene = ctx.upload(spheres=[a, b])
+        ti, _, t = ctx.trace(scene, [[0, 0, 0, 0, 0, -1, 0]])
+        assert t[0] == 2.0 and ti[0] == (0 if first_wins else 1)
+
+
+def test_many_coincident_primitives_do_not_overflow_the_traversal_stack(ctx):
+    spheres = [sphere((0, 0, -3), 1.0, i, ti=0, oi=i) for i in range(300)]
+    scene = ctx.upload(spheres=spheres)
+    _, oi, t = ctx.trace(scene, [[0, 0, 0, 0, 0, -1, 0]])
+    assert t[0] == 2.0 and oi[0] == 299
+
+
+def test_rect_and_box_known_answers(ctx):
+    rect = R.Rect(hdr(0, 0, 0), 1, 0.0, 2.0, 0.0, 4.0, 1.0)          # XZ rect at y = 1
+    box = R.Box(hdr(1, 1, 0), (C.c_float * 3)(5, 0, 0), (C.c_float * 3)(6, 2, 3))
+    scene = ctx.upload(rects=[rect], boxes=[box])
+    ti, _, t = ctx.trace(scene, [[2, 0, 1, 0, 1, 0, 0],        # through the rect's edge x == x1: hit
+                                 [2.0001, 0, 1, 0, 1, 0, 0],   # just outside
+                                 [5.5, 1, -1, 0, 0, 1, 0],     # box front face
+                                 [5.5, 1, 1, 1, 0, 0, 0]])     # from inside the box
+    assert list(ti) == [0, 0xFFFFFFFF, 1, 1]
+    assert t[0] == 1.0 and t[2] == 1.0 and t[3] == 0.5
+
+
+def test_translate_and_rotate_wrappers(ctx):
+    """A sphere at the origin wrapped in Translate((0,0,-4)) is hit like a sphere at (0,0,-4) (transforms.rs:15-24);
+    Rotate by 90 degrees about y maps the object-space point (0,0,3) to world (3,0,0) (transforms.rs:97-101)."""
+    ops = [R.ChainOp(0, (C.c_float * 3)(0, 0, -4)), R.ChainOp(1, (C.c_float * 3)(1.0, 0.0, 0.0))]
+    chains = [R.Chain(0, 0), R.Chain(0, 1), R.Chain(1, 1)]
+    scene = ctx.upload(spheres=[sphere((0, 0, 0), 1.0, 0, ti=0, chain=1), sphere((0, 0, 3), 0.5, 1, ti=1, chain=2)],
+                       chains=chains, chain_ops=ops)
+    ti, _, t = ctx.trace(scene, [[0, 0, 0, 0, 0, -1, 0], [0, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 1, 0]])
+    assert list(ti) == [0, 1, 0xFFFFFFFF]
+    assert t[0] == 3.0 and abs(t[1] - 2.5) < 1e-6
+
+
+def test_moving_sphere_time_range_is_enforced(ctx):
+    m = R.MovingSphere(hdr(0), (C.c_float * 3)(0, 0, -3), (C.c_float * 3)(0, 2, -3), 0.0, 1.0, 0.5)
+    scene = ctx.upload(moving=[m], time=(0.0, 1.0))
+    ti, _, t = ctx.trace(scene, [[0, 0, 0, 0, 0, -1, 0.0], [0, 0, 0, 0, 0, -1, 1.0], [0, 2, 0, 0, 0, -1, 1.0]])
+    assert list(ti) == [0, 0xFFFFFFFF, 0] and t[0] == 2.5 and t[2] == 2.5
+    ctx.trace(scene, [[0, 0, 0, 0, 0, -1, 1.5]], expect=1)
+    assert "time" in ctx.error()
+    ctx.render(scene, 8, 8, 1, cam=simple_camera(0.0, 2.0), expect=1)
+
+
+def test_invalid_arguments_are_rejected_with_a_message(ctx):
+    L = ctx.L
+    assert L.mirt_scene_upload(ctx.ctx, None, None) == 1
+    ctx.upload(spheres=[sphere((0, 0, 0), 1.0, 0, material=3)], expect=1)
+    assert "material" in ctx.error()
+    ctx.upload(chains=[R.Chain(0, 1)], expect=1)                      # chains[0] must be empty
+    ctx.upload(chains=[R.Chain(0, 0), R.Chain(0, 5)], chain_ops=[R.ChainOp(0, (C.c_float * 3)(0, 0, 0))] * 5, expect=3)
+    ctx.upload(spheres=[sphere((np.inf, 0, 0), 1.0, 0)], expect=1)
+    scene = ctx.upload(spheres=[sphere((0, 0, -3), 1.0, 0)])
+    ctx.render(scene, 1, 8, 1, expect=1)
+    ctx.render(scene, 8, 8, 0, expect=1)
+    assert "samples_per_pixel" in ctx.error()
+    bad = C.c_void_p()
+    assert L.mirt_context_create(99, C.byref(bad)) == 1 and not bad.value
+    assert L.mirt_last_error(None)
+
+
+def test_render_of_one_emissive_sphere(ctx):
+    """A diffuse light of radiance 2 filling the view: every pixel sums to spp * 2 (material.rs:151-158)."""
+    mats = [R.Material(3, 0, 0.0)]
+    tex = [R.Texture(0, (C.c_float * 3)(2.0, 2.0, 2.0), 0, 0, 0.0, 0)]
+    scene = ctx.upload(spheres=[sphere((0, 0, -3), 2.9, 0)], materials=mats, textures=tex)
+    rgb, sums, st = ctx.render(scene, 8, 8, 5)
+    assert np.allclose(sums, 10.0)
+    assert np.all(rgb == 255)

@@ -1,0 +1,201 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed fixtures.
+
+Bars: closest-hit ids and t are compared bit for bit (f32 +,-,*,/,sqrt only); images that share the oracle's
+Philox streams are compared per pixel (they differ only where libm / fused-order rounding flips a path);
+images with independent seeds are compared by PSNR on the gamma-encoded RGB24 the reference produces,
+tolerance 40 dB as the target metric states.
+"""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import raytracing_amd as R
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    cache = {}
+
+    def get(name, seed=1):
+        key = (name, seed)
+        if key not in cache:
+            cache[key] = (R.ExampleScene(name, scene_seed=seed), O.Scene(name, scene_seed=seed))
+        return cache[key]
+    yield get
+    for g, o in cache.values():
+        g.close()
+        o.close()
+
+
+def random_rays(n, lo, hi, seed, time_lo=0.0, time_hi=1.0):
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((n, 7), F)
+    rays[:, 0:3] = rng.uniform(lo, hi, (n, 3))
+    d = rng.normal(size=(n, 3))
+    rays[:, 3:6] = d * rng.uniform(0.2, 3.0, (n, 1))   # directions are not unit length in the reference either
+    rays[:, 6] = rng.uniform(time_lo, time_hi, n)
+    return rays
+
+
+def assert_same_hits(g, o, rays, exact_t=True):
+    ti, oi, t = g.trace(rays)
+    oti, ooi, ot = o.trace(rays)
+    bad = np.nonzero((ti != oti) | (oi != ooi))[0]
+    assert bad.size == 0, f"{bad.size} of {len(rays)} ids differ, first ray {bad[:3]}: gpu {ti[bad[:3]]},{oi[bad[:3]]} oracle {oti[bad[:3]]},{ooi[bad[:3]]}"
+    if exact_t:
+        assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    else:
+        assert np.allclose(t, ot, rtol=2e-5, atol=0)
+    return ti, oi, t
+
+
+def test_spheres_bvh_primary_hits_bit_exact_vs_fixture_and_oracle(scenes):
+    """Config 2: the 600x337 pixel-centre rays of examples/spheres_bvh; ids and t bits equal the bvh.rs traversal."""
+    g, o = scenes("spheres_bvh")
+    cam, _ = g.camera()
+    rays = R.camera_rays(cam, 600, 337)
+    ocam, _ = o.camera()
+    assert np.array_equal(rays, O.pixel_centre_rays(ocam, 600, 337))
+    ti, oi, t = assert_same_hits(g, o, rays)
+    fx = np.load(GOLD / "spheres_bvh_primary.npz")
+    hit = ti != 0xFFFFFFFF
+    assert np.array_equal(hit, fx["hit"])
+    assert np.array_equal(ti[hit], fx["type_index"][hit].astype(np.uint32))
+    assert np.array_equal(oi[hit], fx["object_index"][hit].astype(np.uint32))
+    assert np.array_equal(t.view(np.uint32), fx["t_bits"])
+    assert 0.5 < hit.mean() < 0.8
+
+
+@pytest.mark.parametrize("name", ["spheres", "spheres_bvh", "cornel_box"])
+def test_primary_and_random_rays_bit_exact(scenes, name):
+    g, o = scenes(name)
+    cam, _ = g.camera()
+    w, h = (200, 112) if name.startswith("spheres") else (160, 160)
+    assert_same_hits(g, o, R.camera_rays(cam, w, h, time=0.25))
+    if name.startswith("spheres"):
+        rays = np.concatenate([random_rays(60000, [-14, 0.0, -14], [14, 3, 14], 3),
+                               random_rays(20000, [-300, 0.01, -300], [300, 40, 300], 4)])
+    else:
+        rays = random_rays(60000, [1, 1, 1], [554, 554, 554], 5)
+    assert_same_hits(g, o, rays)
+
+
+def test_rays_starting_on_surfaces_bit_exact(scenes):
+    """Secondary-ray-like rays: origins are hit points of a first batch (grazing and self-intersection cases)."""
+    g, o = scenes("spheres")
+    first = random_rays(50000, [-12, 0.05, -12], [12, 4, 12], 8)
+    _, _, t = g.trace(first)
+    ok = np.isfinite(t)
+    rays = first[ok].copy()
+    rays[:, 0:3] = (first[ok, 0:3] + first[ok, 3:6] * t[ok, None]).astype(F)
+    rays[:, 3:6] = np.random.default_rng(9).normal(size=(ok.sum(), 3))
+    assert_same_hits(g, o, rays)
+
+
+def test_final_scene_hits(scenes):
+    """Instanced spheres, 400 boxes, rects and the two constant media.  Media t depends on log2 (libm vs
+    device), so t is compared to 2e-5 relative there and bit for bit on surfaces."""
+    g, o = scenes("final_scene")
+    cam, _ = g.camera()
+    rays = np.concatenate([R.camera_rays(cam, 200, 200), random_rays(40000, [-200, 20, -200], [600, 540, 600], 6)])
+    ti, oi, t = g.trace(rays)
+    oti, ooi, ot = o.trace(rays)
+    same = (ti == oti) & (oi == ooi)
+    # a medium boundary decision can flip on the last bit of log2: allow a handful, none on surfaces
+    medium = (oti == 5) | (ti == 5)          # ConstantMedium is the sixth concrete type added (final_scene.rs:122-140)
+    assert np.all(same | medium)
+    assert np.mean(~same) < 2e-4
+    surf = same & ~medium
+    assert np.array_equal(t[surf].view(np.uint32), ot[surf].view(np.uint32))
+    assert np.allclose(t[same], ot[same], rtol=2e-5)
+    assert medium.mean() > 0.02      # the fog is actually exercised
+
+
+def test_synthetic_bvh_scene_bit_exact(scenes):
+    """The random-spheres generator widened to 81x81 cells (6.5 k spheres) through BVH::from_world."""
+    g, o = scenes("synthetic_bvh:40")
+    assert g.primitive_count() == o.object_count() > 6000
+    cam, _ = g.camera()
+    rays = np.concatenate([R.camera_rays(cam, 160, 90), random_rays(30000, [-42, 0.0, -42], [42, 3, 42], 12)])
+    assert_same_hits(g, o, rays)
+
+
+@pytest.mark.parametrize("name,size,spp", [("spheres", (150, 84), 16), ("spheres_bvh", (90, 50), 8),
+                                           ("cornel_box", (96, 96), 32), ("final_scene", (96, 96), 32)])
+def test_same_seed_images_match_per_pixel(scenes, name, size, spp):
+    """The GPU and the oracle read the same Philox streams, so the images agree path by path."""
+    g, o = scenes(name)
+    w, h = size
+    aspect = 0.0 if name.startswith("spheres") else w / h
+    rgb, sums, st = g.render(w, h, spp, aspect=aspect, seed=21, flags=R.MIRT_RENDER_COUNT_WORK)
+    orgb, osums, oseg = o.render(w, h, spp, aspect=aspect, seed=21)
+    assert abs(st["segments"] - oseg) <= max(8, oseg // 20000)
+    diff = np.abs(rgb.astype(int) - orgb.astype(int))
+    assert O.psnr(rgb, orgb) > 55.0
+    assert np.mean(diff > 1) < 2e-3
+    ok = np.isfinite(osums) & np.isfinite(sums)
+    assert ok.mean() > 0.999
+    rel = np.abs(sums[ok] - osums[ok]) / (np.abs(osums[ok]) + 1e-3)
+    assert np.quantile(rel, 0.99) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["spheres", "cornel_box", "final_scene"])
+def test_converged_image_psnr_vs_cpu_fixture(scenes, name):
+    """Independent seeds: GPU render against the committed converged CPU image, PSNR >= 40 dB on RGB24."""
+    fx = np.load(GOLD / f"{name}_converged.npz")
+    w, h, spp = int(fx["width"]), int(fx["height"]), int(fx["spp"])
+    g, _ = scenes(name)
+    rgb, _, _ = g.render(w, h, spp, depth=int(fx["depth"]), aspect=float(fx["aspect"]), seed=99)
+    assert int(fx["seed"]) != 99
+    assert O.psnr(rgb, fx["rgb"]) >= 40.0
+
+
+def test_sample_ranges_add_up_and_runs_repeat(scenes):
+    """Sharding property at the benchmark's resolution: samples [0,4) + [4,6) == [0,6) up to f32 summation
+    order, and two identical calls agree (atomics reorder the per-pixel sums only)."""
+    g, _ = scenes("final_scene")
+    w, h = 1920, 1080
+    full = g.render(w, h, 6, aspect=w / h, seed=3)[1]
+    again = g.render(w, h, 6, aspect=w / h, seed=3, path_pool=1 << 20)[1]
+    lo = g.render(w, h, 4, aspect=w / h, seed=3, first_sample=0)[1]
+    hi = g.render(w, h, 2, aspect=w / h, seed=3, first_sample=4)[1]
+    ok = np.isfinite(full)
+    assert ok.mean() > 0.9999
+    assert np.array_equal(np.isfinite(again), ok)
+    assert np.allclose(again[ok], full[ok], rtol=1e-4, atol=1e-5)
+    both = ok & np.isfinite(lo) & np.isfinite(hi)
+    assert np.allclose((lo + hi)[both], full[both], rtol=1e-4, atol=1e-5)
+    other = g.render(w, h, 6, aspect=w / h, seed=4)[1]
+    assert not np.allclose(other[ok], full[ok], rtol=1e-4, atol=1e-5)
+
+
+def test_resolve_matches_reference_encoding(scenes):
+    """renderer.rs:232-259 on the device against the oracle's encoder, special values included."""
+    import torch
+    g, _ = scenes("cornel_box")
+    rng = np.random.default_rng(2)
+    w, h, spp = 64, 48, 7
+    sums = (rng.uniform(0, 12, (h, w, 3)) ** 2).astype(F)
+    sums.reshape(-1)[:8] = [0.0, -0.0, np.nan, np.inf, -np.inf, -3.0, 7.0 * 0.999 ** 2, 1e-30]
+    d_sum = torch.from_numpy(sums).cuda()
+    d_rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    g.resolve(d_sum.data_ptr(), w, h, spp, d_rgb.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_rgb.cpu().numpy(), O.encode(sums, spp))
+
+
+def test_depth_limits_and_background(scenes):
+    g, o = scenes("spheres")
+    rgb, sums, st = g.render(32, 18, 4, depth=0)
+    assert not sums.any() and not rgb.any()
+    rgb, sums, st = g.render(32, 18, 4, depth=1, seed=5)
+    orgb, osums, _ = o.render(32, 18, 4, depth=1, seed=5)
+    assert np.allclose(sums, osums, rtol=1e-5, atol=1e-6)
+    assert np.allclose(sums[0] / 4, 0.8, atol=1e-6)     # sky row: background (renderer.rs:187-189)

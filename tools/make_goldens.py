@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Generates the fixtures under tests/golden/ with the CPU oracle (oracle/liboracle.so).
+
+The reference ships no golden vectors for this path and cannot be built here, so the
+fixtures are outputs of the oracle (the C++ restatement of the reference), made once in
+the build container:
+
+  spheres_bvh_primary.npz   closest-hit (type_index, object_index, t bits) of the 600x337
+                            pixel-centre rays of examples/spheres_bvh through the oracle's
+                            bvh.rs traversal, scene seed 1
+  <scene>_converged.npz     low-resolution, high-spp renders (RGB24 + spp + seed) used as
+                            the converged CPU image for PSNR checks
+
+Usage: python tools/make_goldens.py [primary] [spheres] [cornel_box] [final_scene]
+"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib as O  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+GOLD.mkdir(exist_ok=True)
+SEED = 1234
+CONVERGED = {  # name: (width, height, spp)
+    "spheres": (96, 54, 4096),
+    "cornel_box": (64, 64, 16384),
+    "final_scene": (64, 36, 16384),
+}
+
+what = sys.argv[1:] or ["primary"] + list(CONVERGED)
+if "primary" in what:
+    s = O.Scene("spheres_bvh", scene_seed=1)
+    cam, _ = s.camera()
+    rays = O.pixel_centre_rays(cam, 600, 337)
+    ti, oi, t = s.trace(rays)
+    np.savez_compressed(GOLD / "spheres_bvh_primary.npz", type_index=ti.astype(np.uint8), object_index=oi.astype(np.uint16),
+                        hit=(ti != 0xFFFFFFFF), t_bits=t.view(np.uint32), width=600, height=337, scene_seed=1)
+    print("primary", np.mean(ti != 0xFFFFFFFF))
+for name, (w, h, spp) in CONVERGED.items():
+    if name not in what:
+        continue
+    t0 = time.time()
+    s = O.Scene(name, scene_seed=1)
+    rgb, sums, seg = s.render(w, h, spp, aspect=w / h, seed=SEED)
+    np.savez_compressed(GOLD / f"{name}_converged.npz", rgb=rgb, width=w, height=h, spp=spp, seed=SEED, scene_seed=1,
+                        depth=s.depth, aspect=np.float32(w / h))
+    print(name, w, h, spp, round(time.time() - t0, 1), "s", flush=True)
