@@ -8,8 +8,8 @@ the build container:
   spheres_bvh_primary.npz   closest-hit (type_index, object_index, t bits) of the 600x337
                             pixel-centre rays of examples/spheres_bvh through the oracle's
                             bvh.rs traversal, scene seed 1
-  <scene>_converged.npz     low-resolution, high-spp renders (RGB24 + spp + seed) used as
-                            the converged CPU image for PSNR checks
+  <scene>_converged.npz     low-resolution, high-spp renders (RGB24 + mask of NaN-poisoned pixels + spp +
+                            seed) used as the converged CPU image for PSNR checks
 
 Usage: python tools/make_goldens.py [primary] [spheres] [cornel_box] [final_scene]
 """
@@ -47,6 +47,9 @@ for name, (w, h, spp) in CONVERGED.items():
     t0 = time.time()
     s = O.Scene(name, scene_seed=1)
     rgb, sums, seg = s.render(w, h, spp, aspect=w / h, seed=SEED)
-    np.savez_compressed(GOLD / f"{name}_converged.npz", rgb=rgb, width=w, height=h, spp=spp, seed=SEED, scene_seed=1,
+    # a NaN sample blackens its pixel (renderer.rs:241-252); which pixels get one depends on the random
+    # streams, so they are recorded and left out of PSNR comparisons
+    nan_mask = ~np.isfinite(sums).all(axis=2)
+    np.savez_compressed(GOLD / f"{name}_converged.npz", rgb=rgb, nan_mask=nan_mask, width=w, height=h, spp=spp, seed=SEED, scene_seed=1,
                         depth=s.depth, aspect=np.float32(w / h))
     print(name, w, h, spp, round(time.time() - t0, 1), "s", flush=True)
