@@ -270,6 +270,9 @@ typedef struct mirt_render_params {
 } mirt_render_params;
 
 enum { MIRT_KERNEL_EXTEND = 0, MIRT_KERNEL_SHADE = 1, MIRT_KERNEL_RESOLVE = 2, MIRT_KERNEL_COUNT = 4 };
+/* phases of the extend kernel timed by MIRT_RENDER_COUNT_WORK */
+enum { MIRT_PHASE_LOAD = 0, MIRT_PHASE_NODES = 1, MIRT_PHASE_PRIMS = 2, MIRT_PHASE_MEDIA = 3, MIRT_PHASE_WRITE = 4,
+       MIRT_PHASE_TOTAL = 5, MIRT_PHASE_COUNT = 6 };
 
 typedef struct mirt_stats {
   double render_ms;       /* wall time of the render call's device work */
@@ -281,6 +284,7 @@ typedef struct mirt_stats {
   uint32_t path_pool;
   double kernel_ms[MIRT_KERNEL_COUNT];         /* summed device time per kernel (MIRT_RENDER_TIME_KERNELS) */
   uint32_t kernel_launches[MIRT_KERNEL_COUNT];
+  uint64_t extend_phase_cycles[MIRT_PHASE_COUNT]; /* shader-clock cycles summed over waves (MIRT_RENDER_COUNT_WORK) */
 } mirt_stats;
 
 typedef struct mirt_ray {

@@ -128,14 +128,16 @@ class Stats(C.Structure):
     _fields_ = [("render_ms", C.c_double), ("samples", C.c_uint64), ("segments", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64), ("iterations", C.c_uint32),
                 ("path_pool", C.c_uint32), ("kernel_ms", C.c_double * MIRT_KERNEL_COUNT),
-                ("kernel_launches", C.c_uint32 * MIRT_KERNEL_COUNT)]
+                ("kernel_launches", C.c_uint32 * MIRT_KERNEL_COUNT),
+                ("extend_phase_cycles", C.c_uint64 * 6)]
 
     def as_dict(self):
         return {"render_ms": self.render_ms, "samples": int(self.samples), "segments": int(self.segments),
                 "nodes_visited": int(self.nodes_visited), "prims_tested": int(self.prims_tested),
                 "iterations": int(self.iterations), "path_pool": int(self.path_pool),
                 "kernel_ms": [float(x) for x in self.kernel_ms],
-                "kernel_launches": [int(x) for x in self.kernel_launches]}
+                "kernel_launches": [int(x) for x in self.kernel_launches],
+                "extend_phase_cycles": [int(x) for x in self.extend_phase_cycles]}
 
 
 class Ray(C.Structure):

@@ -110,13 +110,18 @@ __device__ __forceinline__ float rng_at(Rng& r, uint32_t index) {  // uniform in
 __device__ __forceinline__ float rng_next(Rng& r) { return rng_at(r, r.next++); }
 __device__ __forceinline__ float rng_range(Rng& r, float lo, float hi) { return lo + (hi - lo) * rng_next(r); }
 
+__device__ __forceinline__ uint4 as_uint4(float4 f) {
+  return make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
+}
+// info quad of a primitive record: material word, chain, order, flags
 __device__ __forceinline__ uint4 prim_info(const DeviceScene& sc, uint32_t ref) {
-  const uint32_t tag = ref_tag(ref);
-  const uint4* p = tag == TAG_SPHERE ? sc.info_sphere
-                   : tag == TAG_MOVING_SPHERE ? sc.info_msphere
-                   : tag == TAG_RECT ? sc.info_rect
-                                     : sc.info_box;
-  return p[ref_index(ref)];
+  const uint32_t tag = ref_tag(ref), idx = ref_index(ref);
+  float4 f;
+  if (tag == TAG_SPHERE) f = sc.sphere[SPHERE_STRIDE * (size_t)idx + 1];
+  else if (tag == TAG_MOVING_SPHERE) f = sc.msphere[MSPHERE_STRIDE * (size_t)idx + 3];
+  else if (tag == TAG_RECT) f = sc.rect[RECT_STRIDE * (size_t)idx + 2];
+  else f = sc.box[BOX_STRIDE * (size_t)idx + 2];
+  return as_uint4(f);
 }
 __device__ __forceinline__ uint2 prim_ids(const DeviceScene& sc, uint32_t ref) {
   const uint32_t tag = ref_tag(ref);
@@ -215,40 +220,42 @@ __device__ __forceinline__ bool box_t(V3 mn, V3 mx, const Ray& r, float t_min, f
   return any;
 }
 
-// t of primitive `ref` for ray r (already in the primitive's object space).
-__device__ __forceinline__ bool prim_t_local(const DeviceScene& sc, uint32_t ref, const Ray& r, float t_min,
-                                             float t_max, float& t) {
+// t of primitive `ref` for the world-space ray r.  The info quad of the record
+// shares a cache line with the geometry, so looking up the wrapper chain costs
+// no second round trip; the ray goes through the chain in front of the test.
+// `info` receives the record's info quad (material word, chain, order, flags).
+__device__ __forceinline__ bool prim_t(const DeviceScene& sc, uint32_t ref, const Ray& r, float t_min, float t_max,
+                                       float& t, uint4& info) {
   const uint32_t tag = ref_tag(ref), idx = ref_index(ref);
   if (tag == TAG_SPHERE) {
-    const float4 g = sc.sphere[idx];
+    const float4* p = sc.sphere + SPHERE_STRIDE * (size_t)idx;
+    const float4 g = p[0];
+    info = as_uint4(p[1]);
+    if (info.y != 0) return sphere_t(xyz(g), g.w, chain_forward(sc, info.y, r), t_min, t_max, t);
     return sphere_t(xyz(g), g.w, r, t_min, t_max, t);
   } else if (tag == TAG_MOVING_SPHERE) {
-    const float4 m0 = sc.msphere[3 * idx], m1 = sc.msphere[3 * idx + 1], m2 = sc.msphere[3 * idx + 2];
-    return sphere_t(moving_center(m0, m1, m2, r.time), m0.w, r, t_min, t_max, t);
+    const float4* p = sc.msphere + MSPHERE_STRIDE * (size_t)idx;
+    const float4 m0 = p[0], m1 = p[1], m2 = p[2];
+    info = as_uint4(p[3]);
+    const Ray lr = info.y != 0 ? chain_forward(sc, info.y, r) : r;
+    return sphere_t(moving_center(m0, m1, m2, lr.time), m0.w, lr, t_min, t_max, t);
   } else if (tag == TAG_RECT) {
-    const float4 g0 = sc.rect[2 * idx], g1 = sc.rect[2 * idx + 1];
+    const float4* p = sc.rect + RECT_STRIDE * (size_t)idx;
+    const float4 g0 = p[0], g1 = p[1];
+    info = as_uint4(p[2]);
+    const Ray lr = info.y != 0 ? chain_forward(sc, info.y, r) : r;
     float pa, pb;
-    const bool ok = rect_t(__float_as_uint(g1.y), g0.x, g0.y, g0.z, g0.w, g1.x, r, t_min, t_max, t, pa, pb);
+    const bool ok = rect_t(__float_as_uint(g1.y), g0.x, g0.y, g0.z, g0.w, g1.x, lr, t_min, t_max, t, pa, pb);
     return ok && !(t != t);
   } else {
-    const float4 g0 = sc.box[2 * idx], g1 = sc.box[2 * idx + 1];
+    const float4* p = sc.box + BOX_STRIDE * (size_t)idx;
+    const float4 g0 = p[0], g1 = p[1];
+    info = as_uint4(p[2]);
+    const Ray lr = info.y != 0 ? chain_forward(sc, info.y, r) : r;
     int face;
     float pa, pb;
-    return box_t(xyz(g0), xyz(g1), r, t_min, t_max, t, face, pa, pb);
+    return box_t(xyz(g0), xyz(g1), lr, t_min, t_max, t, face, pa, pb);
   }
-}
-
-// Same with the primitive's wrappers applied to the world-space ray first.
-__device__ __forceinline__ bool prim_t(const DeviceScene& sc, uint32_t ref, const Ray& r, float t_min, float t_max,
-                                       float& t) {
-  if (sc.n_chains > 1) {
-    const uint32_t chain = prim_info(sc, ref).y;
-    if (chain != 0) {
-      const Ray lr = chain_forward(sc, chain, r);
-      return prim_t_local(sc, ref, lr, t_min, t_max, t);
-    }
-  }
-  return prim_t_local(sc, ref, r, t_min, t_max, t);
 }
 
 // ---- conservative box test ------------------------------------------------------
@@ -270,55 +277,108 @@ __device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min
 
 struct Work {
   uint32_t nodes, prims;
+  long long cycles[MIRT_PHASE_COUNT];
 };
 
 // Closest surface over (t_min, inf): the result of the reference's exhaustive
 // scan -- smallest t, and of equal t the primitive with the higher `order`.
+// `nodes` is the node array (in LDS or in global memory, the caller decides);
+// `stack` is this lane's column of an LDS stack whose rows are `stride` words apart.
+// Two nested loops: a lane walks inner nodes until it holds a leaf, the wave
+// then tests the leaves its lanes hold together.
 template <bool COUNT>
-__device__ __forceinline__ void closest_surface(const DeviceScene& sc, const Ray& r, float t_min, uint32_t* stack,
-                                                uint32_t& best_ref, float& best_t, Work& work) {
+__device__ __forceinline__ void closest_surface(const DeviceScene& sc, const float4* nodes, const Ray& r, float t_min,
+                                                uint32_t* stack, uint32_t stride, uint32_t& best_ref, float& best_t,
+                                                uint32_t& best_material, Work& work) {
   best_ref = REF_NONE;
   best_t = kInf;
-  uint32_t cur = sc.root_ref;
+  best_material = 0;
+  uint32_t best_order = 0;
+  uint32_t cur = sc.root_ref;  // REF_NONE (a leaf-tagged sentinel) doubles as "no work left"
   if (cur == REF_NONE) return;
   const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-  int sp = 0;
+  uint32_t sp = 0;
   for (;;) {
-    if (cur & REF_LEAF) {
-      float t;
-      if (COUNT) ++work.prims;
-      if (prim_t(sc, cur, r, t_min, best_t, t)) {
-        bool take = t < best_t || best_ref == REF_NONE;
-        if (!take) {  // t == best_t: the later one in the reference's visiting order wins
-          const uint32_t o_new = prim_info(sc, cur).z;
-          const uint32_t o_old = prim_info(sc, best_ref).z;
-          take = o_new > o_old;
-        }
-        if (take) { best_t = t; best_ref = cur; }
+    long long t0 = 0, t1 = 0;
+    if (COUNT) t0 = clock64();
+    while (!(cur & REF_LEAF)) {
+      if (COUNT) ++work.nodes;
+      const float4* n = nodes + 4 * (size_t)cur;
+      const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+      float tl, tr;
+      const bool hl = slab(xyz(n0), xyz(n1), r.o, inv, t_min, best_t, tl);
+      const bool hr = slab(xyz(n2), xyz(n3), r.o, inv, t_min, best_t, tr);
+      const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
+      if (hl && hr) {
+        const bool left_first = tl <= tr;
+        stack[(sp++) * stride] = left_first ? right : left;
+        cur = left_first ? left : right;
+      } else if (hl) {
+        cur = left;
+      } else if (hr) {
+        cur = right;
+      } else {
+        cur = sp ? stack[(--sp) * stride] : REF_NONE;
       }
-      if (sp == 0) break;
-      cur = stack[(--sp) * BLOCK_THREADS];
-      continue;
     }
-    if (COUNT) ++work.nodes;
-    const float4* n = sc.nodes + 4 * (size_t)cur;
-    const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-    float tl, tr;
-    const bool hl = slab(xyz(n0), xyz(n1), r.o, inv, t_min, best_t, tl);
-    const bool hr = slab(xyz(n2), xyz(n3), r.o, inv, t_min, best_t, tr);
-    const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
-    if (hl && hr) {
-      const bool left_first = tl <= tr;
-      stack[(sp++) * BLOCK_THREADS] = left_first ? right : left;
-      cur = left_first ? left : right;
-    } else if (hl) {
-      cur = left;
-    } else if (hr) {
-      cur = right;
-    } else {
-      if (sp == 0) break;
-      cur = stack[(--sp) * BLOCK_THREADS];
+    if (COUNT) { t1 = clock64(); work.cycles[MIRT_PHASE_NODES] += t1 - t0; }
+    if (cur == REF_NONE) break;
+    float t;
+    uint4 info;
+    if (COUNT) ++work.prims;
+    if (prim_t(sc, cur, r, t_min, best_t, t, info)) {
+      // t == best_t: the later one in the reference's visiting order wins
+      if (t < best_t || best_ref == REF_NONE || info.z > best_order) {
+        best_t = t; best_ref = cur; best_material = info.x; best_order = info.z;
+      }
     }
+    cur = sp ? stack[(--sp) * stride] : REF_NONE;
+    if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - t1;
+  }
+}
+
+// Both roots of the sphere quadratic (objects.rs:42-53), or false when the discriminant is negative.
+__device__ __forceinline__ bool sphere_roots(V3 center, float radius, const Ray& r, float& r1, float& r2) {
+  const V3 os = r.o - center;
+  const float a = len2(r.d);
+  const float half_b = dot(os, r.d);
+  const float c = len2(os) - radius * radius;
+  const float disc = half_b * half_b - a * c;
+  if (disc < 0.0f) return false;
+  const float sq = sqrtf(disc);
+  r1 = (-half_b - sq) / a;
+  r2 = (-half_b + sq) / a;
+  return true;
+}
+
+// What closest_media needs of one constant medium, staged once per block in LDS.
+struct MediumEntry {
+  float4 boundary;        // sphere boundary: center, radius
+  uint32_t boundary_ref;
+  uint32_t boundary_chain;
+  uint32_t chain;         // wrappers around the medium itself
+  uint32_t material_word;
+  float neg_inv_density;
+  uint32_t pad[3];
+};
+
+__device__ __forceinline__ void stage_media(const DeviceScene& sc, MediumEntry* table) {
+  if (threadIdx.x < sc.n_media) {
+    const DMedium med = sc.media[threadIdx.x];
+    MediumEntry e;
+    e.boundary = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    e.boundary_ref = med.boundary_ref;
+    e.boundary_chain = 0;
+    if (ref_tag(med.boundary_ref) == TAG_SPHERE) {
+      const float4* p = sc.sphere + SPHERE_STRIDE * (size_t)ref_index(med.boundary_ref);
+      e.boundary = p[0];
+      e.boundary_chain = __float_as_uint(p[1].y);
+    }
+    e.chain = med.chain;
+    e.material_word = med.material_word;
+    e.neg_inv_density = med.neg_inv_density;
+    e.pad[0] = e.pad[1] = e.pad[2] = 0;
+    table[threadIdx.x] = e;
   }
 }
 
@@ -326,13 +386,30 @@ __device__ __forceinline__ void closest_surface(const DeviceScene& sc, const Ray
 // Medium m reads draw m of the STAGE_MEDIA stream, so the order media are
 // visited in does not matter; an accepted medium hit replaces the current
 // closest hit exactly as World::hit does with its shrinking t_max.
-__device__ __forceinline__ void closest_media(const DeviceScene& sc, const Ray& r, float t_min, Rng& rng,
-                                              uint32_t& best_ref, float& best_t) {
+__device__ __forceinline__ void closest_media(const DeviceScene& sc, const MediumEntry* table, const Ray& r,
+                                              float t_min, Rng& rng, uint32_t& best_ref, float& best_t,
+                                              uint32_t& best_material) {
   for (uint32_t m = 0; m < sc.n_media; ++m) {
-    const DMedium med = sc.media[m];
+    const MediumEntry med = table[m];
     float h1, h2;
-    if (!prim_t(sc, med.boundary_ref, r, -kInf, kInf, h1)) continue;
-    if (!prim_t(sc, med.boundary_ref, r, h1 + 0.0001f, kInf, h2)) continue;
+    if (ref_tag(med.boundary_ref) == TAG_SPHERE) {
+      // The reference intersects the boundary twice, over (-inf, inf) and over (h1 + 0.0001, inf); both
+      // calls solve the same quadratic, so the roots are computed once and picked as Sphere::hit would.
+      const Ray lr = med.boundary_chain != 0 ? chain_forward(sc, med.boundary_chain, r) : r;
+      float r1, r2;
+      if (!sphere_roots(xyz(med.boundary), med.boundary.w, lr, r1, r2)) continue;
+      if (in_range(r1, -kInf, kInf)) h1 = r1;
+      else if (in_range(r2, -kInf, kInf)) h1 = r2;
+      else continue;
+      const float t2_min = h1 + 0.0001f;
+      if (in_range(r1, t2_min, kInf)) h2 = r1;
+      else if (in_range(r2, t2_min, kInf)) h2 = r2;
+      else continue;
+    } else {
+      uint4 info;
+      if (!prim_t(sc, med.boundary_ref, r, -kInf, kInf, h1, info)) continue;
+      if (!prim_t(sc, med.boundary_ref, r, h1 + 0.0001f, kInf, h2, info)) continue;
+    }
     if (h1 < t_min) h1 = t_min;
     if (h2 > best_t) h2 = best_t;
     if (h1 >= h2) continue;
@@ -344,6 +421,7 @@ __device__ __forceinline__ void closest_media(const DeviceScene& sc, const Ray& 
     if (hit_distance > dist_inside) continue;
     best_t = h1 + hit_distance / ray_length;
     best_ref = make_leaf(TAG_MEDIUM, m);
+    best_material = med.material_word;
   }
 }
 
@@ -428,19 +506,20 @@ __device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, c
     h.u = 0.0f; h.v = 0.0f;
     h.front = true;
   } else if (tag == TAG_SPHERE) {
-    const float4 g = sc.sphere[idx];
+    const float4 g = sc.sphere[SPHERE_STRIDE * (size_t)idx];
     sphere_record(xyz(g), g.w, r, t_found, h);
   } else if (tag == TAG_MOVING_SPHERE) {
-    const float4 m0 = sc.msphere[3 * idx], m1 = sc.msphere[3 * idx + 1], m2 = sc.msphere[3 * idx + 2];
+    const float4* mp = sc.msphere + MSPHERE_STRIDE * (size_t)idx;
+    const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
     sphere_record(moving_center(m0, m1, m2, r.time), m0.w, r, t_found, h);
   } else if (tag == TAG_RECT) {
-    const float4 g0 = sc.rect[2 * idx], g1 = sc.rect[2 * idx + 1];
+    const float4 g0 = sc.rect[RECT_STRIDE * (size_t)idx], g1 = sc.rect[RECT_STRIDE * (size_t)idx + 1];
     const uint32_t axis = __float_as_uint(g1.y);
     float t, pa = 0.0f, pb = 0.0f;
     rect_t(axis, g0.x, g0.y, g0.z, g0.w, g1.x, r, kTMin, kInf, t, pa, pb);
     rect_record(axis, g0.x, g0.y, g0.z, g0.w, r, t_found, pa, pb, h);
   } else {
-    const float4 g0 = sc.box[2 * idx], g1 = sc.box[2 * idx + 1];
+    const float4 g0 = sc.box[BOX_STRIDE * (size_t)idx], g1 = sc.box[BOX_STRIDE * (size_t)idx + 1];
     const V3 mn = xyz(g0), mx = xyz(g1);
     float t, pa = 0.0f, pb = 0.0f;
     int face = 0;
@@ -699,170 +778,257 @@ __device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t 
   y = band * 8u + (in_band - x * rows);
 }
 
+// Exclusive prefix sum over the 64 lanes of a wave; `total` receives the sum.
+__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(inc, off);
+    if ((int)lane_id() >= off) inc += up;
+  }
+  total = __shfl(inc, 63);
+  return inc - v;
+}
+
 // ---- extend -----------------------------------------------------------------------
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK_THREADS) void k_extend(DeviceScene sc, RenderConst rc, float4* __restrict__ cur,
-                                                          IterCounters* counters, int parity, WorkCounters* work_out,
-                                                          uint32_t* __restrict__ queues) {
-  __shared__ uint32_t stack_mem[STACK_DEPTH * BLOCK_THREADS];
-  uint32_t* stack = stack_mem + threadIdx.x;
+// Block-shared bookkeeping of extend, filled by the first wave.
+struct ExtendShared {
+  uint32_t survivors[N_REGIONS];    // region s carries survivors in its local slots [0, survivors[s])
+  uint32_t free_before[N_REGIONS];  // free slots in regions < s: numbers the new paths of region s
+  uint32_t n_new;                   // camera paths started this iteration
+  uint32_t pad[3];
+  MediumEntry media[MIRT_MAX_MEDIA];
+};
+
+// LDS_NODES: the block first stages the whole node array in LDS (dynamic shared memory holds
+// [bookkeeping][nodes][stack]); otherwise nodes are fetched from global memory.
+template <bool COUNT, bool LDS_NODES, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst rc, float4* __restrict__ cur,
+                                                    IterCounters* counters, int parity, WorkCounters* work_out,
+                                                    uint32_t* __restrict__ queues) {
+  extern __shared__ float4 smem[];
+  static_assert(sizeof(ExtendShared) % 16 == 0, "keeps the node array 16-byte aligned");
+  ExtendShared& sh = *reinterpret_cast<ExtendShared*>(smem);
+  float4* after = smem + sizeof(ExtendShared) / 16;
+  const float4* nodes = sc.nodes;
+  uint32_t* stack = reinterpret_cast<uint32_t*>(after) + threadIdx.x;
+  if (LDS_NODES) {
+    const uint32_t n4 = sc.n_nodes * 4u;
+    for (uint32_t k = threadIdx.x; k < n4; k += THREADS) after[k] = sc.nodes[k];
+    nodes = after;
+    stack = reinterpret_cast<uint32_t*>(after + n4) + threadIdx.x;
+  }
 
   IterCounters* c = counters + parity;
   IterCounters* nx = counters + (parity ^ 1);
-  const uint32_t n_surv = c->n_cur;
   const uint64_t issued = c->issued;
-  const uint64_t remaining = rc.total_paths - issued;
-  const uint32_t room = rc.pool - n_surv;
-  const uint32_t n_new = remaining < (uint64_t)room ? (uint32_t)remaining : room;
-  const uint32_t n_tot = n_surv + n_new;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    nx->n_cur = 0;
-    nx->queue_n[0] = 0; nx->queue_n[1] = 0; nx->queue_n[2] = 0; nx->queue_n[3] = 0;
-    nx->issued = issued + n_new;
+  if (threadIdx.x < 64) {  // N_REGIONS == 64: one lane per region
+    const uint32_t n = c->region[threadIdx.x].n_cur;
+    uint32_t total_free;
+    const uint32_t before = wave_exclusive_scan(rc.region_cap - n, total_free);
+    sh.survivors[threadIdx.x] = n;
+    sh.free_before[threadIdx.x] = before;
+    const uint64_t remaining = rc.total_paths - issued;
+    const uint32_t n_new = remaining < (uint64_t)total_free ? (uint32_t)remaining : total_free;
+    if (threadIdx.x == 0) sh.n_new = n_new;
+    if (blockIdx.x == 0) {  // the other parity's counters start the next iteration from zero
+      RegionCounters& z = nx->region[threadIdx.x];
+      z.n_cur = 0;
+      z.queue_n[0] = 0; z.queue_n[1] = 0; z.queue_n[2] = 0; z.queue_n[3] = 0;
+      if (threadIdx.x == 0) nx->issued = issued + n_new;
+    }
   }
-  Work work{0, 0};
+  stage_media(sc, sh.media);
+  __syncthreads();
+
+  Work work{};
+  long long k_begin = 0, ts = 0;
+  if (COUNT) k_begin = clock64();
   uint32_t segments = 0;
-  const uint32_t stride = gridDim.x * BLOCK_THREADS;
+  const uint32_t stride = gridDim.x * THREADS;
   const uint32_t pixels = rc.width * rc.height;
+  const uint32_t n_new = sh.n_new;
   // every lane of a wave runs the same number of rounds so the ballots below see whole waves
-  const uint32_t rounds = (n_tot + stride - 1) / stride;
+  const uint32_t rounds = (rc.pool + stride - 1) / stride;
   for (uint32_t round = 0; round < rounds; ++round) {
-    const uint32_t i = round * stride + blockIdx.x * BLOCK_THREADS + threadIdx.x;
-    const bool active = i < n_tot;
+    const uint32_t i = round * stride + blockIdx.x * THREADS + threadIdx.x;  // slot
+    const uint32_t region = slot_region(i);  // the same for the 64 lanes of a wave
+    const uint32_t local = slot_local(i);
+    bool active = false;
     Ray r;
-    uint32_t pixel = 0, sample = 0, bounce = 0;
-    if (active) {
-      if (i < n_surv) {
+    uint32_t pixel = 0, sample_bounce = 0;
+    if (COUNT) ts = clock64();
+    if (i < rc.pool) {
+      const uint32_t n_surv = sh.survivors[region];
+      if (local < n_surv) {
         const float4 r0 = cur[4 * (size_t)i], r1 = cur[4 * (size_t)i + 1];
-        const float4 r2 = cur[4 * (size_t)i + 2], r3 = cur[4 * (size_t)i + 3];
         r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
-        pixel = __float_as_uint(r2.w);
-        sample = __float_as_uint(r3.x);
-        bounce = __float_as_uint(r3.y);
+        pixel = __float_as_uint(r1.w);
+        if (sc.n_media != 0) sample_bounce = __float_as_uint(cur[4 * (size_t)i + 2].w);
+        active = true;
       } else {
-        // new camera path (renderer.rs:215-218, camera.rs:57-68)
-        const uint64_t g = issued + (uint64_t)(i - n_surv);
-        const uint32_t pass = (uint32_t)(g / pixels);
-        const uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
-        uint32_t x, y;
-        pixel_of(in_pass, rc.width, rc.height, x, y);
-        pixel = y * rc.width + x;
-        sample = rc.first_sample + pass;
-        bounce = 0;
-        Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, rc.key0, rc.key1);
-        const float u = ((float)x + rng_next(rng)) / (float)(rc.width - 1);
-        const float v = ((float)y + rng_next(rng)) / (float)(rc.height - 1);
-        V3 disk;
-        for (;;) {  // vec3.rs:53-60
-          const float dx = rng_range(rng, -1.0f, 1.0f);
-          const float dy = rng_range(rng, -1.0f, 1.0f);
-          disk = v3(dx, dy, 0.0f);
-          if (len2(disk) < 1.0f) break;
+        const uint32_t nth = sh.free_before[region] + (local - n_surv);
+        if (nth < n_new) {
+          // new camera path (renderer.rs:215-218, camera.rs:57-68)
+          const uint64_t g = issued + nth;
+          const uint32_t pass = (uint32_t)(g / pixels);
+          const uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
+          uint32_t x, y;
+          pixel_of(in_pass, rc.width, rc.height, x, y);
+          pixel = y * rc.width + x;
+          const uint32_t sample = rc.first_sample + pass;
+          sample_bounce = sample << 8;
+          Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, rc.key0, rc.key1);
+          const float u = ((float)x + rng_next(rng)) / (float)(rc.width - 1);
+          const float v = ((float)y + rng_next(rng)) / (float)(rc.height - 1);
+          V3 disk;
+          for (;;) {  // vec3.rs:53-60
+            const float dx = rng_range(rng, -1.0f, 1.0f);
+            const float dy = rng_range(rng, -1.0f, 1.0f);
+            disk = v3(dx, dy, 0.0f);
+            if (len2(disk) < 1.0f) break;
+          }
+          const mirt_camera& cam = rc.cam;
+          const V3 rd = rc.cam.lens_radius * disk;
+          const V3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]);
+          const V3 offset = cu * rd.x + cv * rd.y;
+          const V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
+          const V3 llc = v3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
+          const V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+          const V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+          r.d = llc + u * hor + v * ver - origin - offset;
+          r.o = origin + offset;
+          r.time = rng_range(rng, cam.time0, cam.time1);
+          cur[4 * (size_t)i] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
+          cur[4 * (size_t)i + 1] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(pixel));
+          cur[4 * (size_t)i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample_bounce));
+          active = true;
         }
-        const mirt_camera& cam = rc.cam;
-        const V3 rd = rc.cam.lens_radius * disk;
-        const V3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]);
-        const V3 offset = cu * rd.x + cv * rd.y;
-        const V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
-        const V3 llc = v3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
-        const V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
-        const V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
-        r.d = llc + u * hor + v * ver - origin - offset;
-        r.o = origin + offset;
-        r.time = rng_range(rng, cam.time0, cam.time1);
-        cur[4 * (size_t)i] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
-        cur[4 * (size_t)i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(pixel));
       }
     }
-    uint32_t ref = REF_NONE;
+    uint32_t ref = REF_NONE, material = 0;
     float t = kInf;
+    if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_LOAD] += now - ts; ts = now; }
     if (active) {
-      closest_surface<COUNT>(sc, r, kTMin, stack, ref, t, work);
+      closest_surface<COUNT>(sc, nodes, r, kTMin, stack, THREADS, ref, t, material, work);
+      if (COUNT) ts = clock64();
       if (sc.n_media != 0) {
-        Rng rng = rng_begin(pixel, sample, bounce, STAGE_MEDIA, rc.key0, rc.key1);
-        closest_media(sc, r, kTMin, rng, ref, t);
+        Rng rng = rng_begin(pixel, sample_bounce >> 8, sample_bounce & 255u, STAGE_MEDIA, rc.key0, rc.key1);
+        closest_media(sc, sh.media, r, kTMin, rng, ref, t, material);
       }
+      if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_MEDIA] += now - ts; ts = now; }
       ++segments;
-      cur[4 * (size_t)i + 1] = make_float4(r.d.x, r.d.y, r.d.z, t);
-      cur[4 * (size_t)i + 3] =
-          make_float4(__uint_as_float(sample), __uint_as_float(bounce), __uint_as_float(ref), 0.0f);
+      cur[4 * (size_t)i + 3] = make_float4(t, __uint_as_float(ref), 0.0f, 0.0f);
     }
-    // bin by material
-    int q = -1;
-    if (active) {
-      if (ref == REF_NONE) {
-        q = QUEUE_TERMINATE;
-      } else if (ref_tag(ref) == TAG_MEDIUM) {
-        q = queue_of(sc.media[ref_index(ref)].material_word);
-      } else {
-        q = queue_of(prim_info(sc, ref).x);
-      }
+    // Bin by material: the four reservations of the wave go out as one atomic
+    // instruction (lane q adds the count of queue q), all to this region's counters.
+    const int q = !active ? -1 : (ref == REF_NONE ? QUEUE_TERMINATE : queue_of(material));
+    const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
+    const uint32_t lane = lane_id();
+    uint32_t base = 0;
+    if (lane < 4) {
+      const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+      const uint32_t cnt = (uint32_t)__popcll(mine);
+      if (cnt) base = atomicAdd(&c->region[region].queue_n[lane], cnt);
     }
-#pragma unroll
-    for (int k = 0; k < N_QUEUES; ++k) {
-      const bool mine = q == k;
-      const uint32_t slot = wave_reserve(mine, &c->queue_n[k]);
-      if (mine) queues[(size_t)k * rc.pool + slot] = i;
+    const uint32_t b0 = __shfl(base, 0), b1 = __shfl(base, 1), b2 = __shfl(base, 2), b3 = __shfl(base, 3);
+    if (q >= 0) {
+      const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
+      const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
+      const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+      queues[((size_t)q * N_REGIONS + region) * rc.region_cap + pos] = i;
     }
+    if (COUNT) work.cycles[MIRT_PHASE_WRITE] += clock64() - ts;
   }
   if (COUNT) {
-    // one atomic per wave
+    work.cycles[MIRT_PHASE_TOTAL] = clock64() - k_begin;
+    // one atomic per wave; a lane's phase clocks stop when it leaves a loop early, so the wave's time is the max
     for (int off = 32; off > 0; off >>= 1) {
       work.nodes += __shfl_down(work.nodes, off);
       work.prims += __shfl_down(work.prims, off);
       segments += __shfl_down(segments, off);
+      for (int k = 0; k < MIRT_PHASE_COUNT; ++k) {
+        const long long other = __shfl_down(work.cycles[k], off);
+        work.cycles[k] = other > work.cycles[k] ? other : work.cycles[k];
+      }
     }
     if (lane_id() == 0) {
       atomicAdd(&work_out->nodes, (unsigned long long)work.nodes);
       atomicAdd(&work_out->prims, (unsigned long long)work.prims);
       atomicAdd(&work_out->segments, (unsigned long long)segments);
+      for (int k = 0; k < MIRT_PHASE_COUNT; ++k) atomicAdd(&work_out->cycles[k], (unsigned long long)work.cycles[k]);
     }
   }
 }
 
 // ---- shade ------------------------------------------------------------------------
+constexpr uint32_t N_SEGMENTS = N_QUEUES * N_REGIONS;  // one per (material queue, region), queue-major
+
 __global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderConst rc,
                                                          const float4* __restrict__ cur, float4* __restrict__ next,
                                                          IterCounters* counters, int parity,
                                                          const uint32_t* __restrict__ queues,
                                                          float* __restrict__ rgb_sum) {
+  // All segments laid end to end, each starting on a wave boundary: a wave shades one
+  // material of one region.  seg_start[k] = first virtual index of segment k.
+  __shared__ uint32_t seg_start[N_SEGMENTS + 1];
+  __shared__ uint32_t seg_count[N_SEGMENTS];
   IterCounters* c = counters + parity;
   IterCounters* nx = counters + (parity ^ 1);
-  // the four queues laid end to end, each starting at a wave boundary so a wave shades one material
-  const uint32_t n0 = c->queue_n[0], n1 = c->queue_n[1], n2 = c->queue_n[2], n3 = c->queue_n[3];
-  const uint32_t p1 = (n0 + 63u) & ~63u;
-  const uint32_t p2 = p1 + ((n1 + 63u) & ~63u);
-  const uint32_t p3 = p2 + ((n2 + 63u) & ~63u);
-  const uint32_t total = p3 + n3;
+  if (threadIdx.x < 64) {  // each lane of the first wave owns N_SEGMENTS / 64 consecutive segments
+    constexpr uint32_t PER = N_SEGMENTS / 64;
+    uint32_t cnt[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t seg = threadIdx.x * PER + k;
+      cnt[k] = c->region[seg % N_REGIONS].queue_n[seg / N_REGIONS];
+      sum += (cnt[k] + 63u) & ~63u;
+    }
+    uint32_t total;
+    uint32_t start = wave_exclusive_scan(sum, total);
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t seg = threadIdx.x * PER + k;
+      seg_start[seg] = start;
+      seg_count[seg] = cnt[k];
+      start += (cnt[k] + 63u) & ~63u;
+    }
+    if (threadIdx.x == 63) seg_start[N_SEGMENTS] = total;
+  }
+  __syncthreads();
+  const uint32_t total = seg_start[N_SEGMENTS];
   const uint32_t stride = gridDim.x * BLOCK_THREADS;
   const uint32_t rounds = (total + stride - 1) / stride;
   for (uint32_t round = 0; round < rounds; ++round) {
     const uint32_t j = round * stride + blockIdx.x * BLOCK_THREADS + threadIdx.x;
-    int q;
-    uint32_t k;
-    if (j < p1) { q = 0; k = j; }
-    else if (j < p2) { q = 1; k = j - p1; }
-    else if (j < p3) { q = 2; k = j - p2; }
-    else { q = 3; k = j - p3; }
-    const uint32_t qn = q == 0 ? n0 : (q == 1 ? n1 : (q == 2 ? n2 : n3));
-    const bool active = j < total && k < qn;
+    // segment of this wave: the last one starting at or before its first virtual index
+    const uint32_t j0 = j & ~63u;
+    uint32_t lo = 0, hi = N_SEGMENTS;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (seg_start[mid] <= j0) lo = mid; else hi = mid;
+    }
+    const uint32_t seg = lo;
+    const uint32_t q = seg / N_REGIONS, region = seg % N_REGIONS;
+    const uint32_t k = j - seg_start[seg];
+    const bool active = j < total && k < seg_count[seg];
 
     bool alive = false;
     Ray nr;
     V3 beta = v3(0.0f, 0.0f, 0.0f);
     uint32_t pixel = 0, sample = 0, bounce = 0;
     if (active) {
-      const uint32_t i = queues[(size_t)q * rc.pool + k];
+      const uint32_t i = queues[((size_t)q * N_REGIONS + region) * rc.region_cap + k];
       const float4 r0 = cur[4 * (size_t)i], r1 = cur[4 * (size_t)i + 1];
       const float4 r2 = cur[4 * (size_t)i + 2], r3 = cur[4 * (size_t)i + 3];
       Ray r;
       r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
-      const float t = r1.w;
+      pixel = __float_as_uint(r1.w);
       beta = xyz(r2);
-      pixel = __float_as_uint(r2.w);
-      sample = __float_as_uint(r3.x);
-      bounce = __float_as_uint(r3.y);
-      const uint32_t ref = __float_as_uint(r3.z);
+      sample = __float_as_uint(r2.w) >> 8;
+      bounce = __float_as_uint(r2.w) & 255u;
+      const float t = r3.x;
+      const uint32_t ref = __float_as_uint(r3.y);
 
       V3 term = v3(0.0f, 0.0f, 0.0f);  // radiance that ends the path
       if (ref == REF_NONE) {
@@ -930,13 +1096,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderC
         }
       }
     }
-    const uint32_t slot = wave_reserve(alive, &nx->n_cur);
+    // survivors are compacted into the same region of the other buffer (one atomic per wave)
+    const uint32_t local = wave_reserve(alive, &nx->region[region].n_cur);
     if (alive) {
-      next[4 * (size_t)slot] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
-      next[4 * (size_t)slot + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, 0.0f);
-      next[4 * (size_t)slot + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float(pixel));
-      next[4 * (size_t)slot + 3] =
-          make_float4(__uint_as_float(sample), __uint_as_float(bounce + 1), __uint_as_float(REF_NONE), 0.0f);
+      const size_t slot = region_slot(region, local);
+      next[4 * slot] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
+      next[4 * slot + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
+      next[4 * slot + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
     }
   }
 }
@@ -962,7 +1128,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
                                                          uint32_t* __restrict__ type_index,
                                                          uint32_t* __restrict__ object_index, float* __restrict__ t_out) {
   __shared__ uint32_t stack_mem[STACK_DEPTH * BLOCK_THREADS];
+  __shared__ MediumEntry media[MIRT_MAX_MEDIA];
   uint32_t* stack = stack_mem + threadIdx.x;
+  stage_media(sc, media);
+  __syncthreads();
   const size_t i = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
   if (i >= n) return;
   const mirt_ray in = rays[i];
@@ -970,13 +1139,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
   r.o = v3(in.origin[0], in.origin[1], in.origin[2]);
   r.d = v3(in.direction[0], in.direction[1], in.direction[2]);
   r.time = in.time;
-  uint32_t ref;
+  uint32_t ref, material;
   float t;
-  Work work{0, 0};
-  closest_surface<false>(sc, r, kTMin, stack, ref, t, work);
+  Work work{};
+  closest_surface<false>(sc, sc.nodes, r, kTMin, stack, BLOCK_THREADS, ref, t, material, work);
   if (sc.n_media != 0) {
     Rng rng = rng_begin((uint32_t)i, 0, 0, STAGE_MEDIA, key0, key1);
-    closest_media(sc, r, kTMin, rng, ref, t);
+    closest_media(sc, media, r, kTMin, rng, ref, t, material);
   }
   uint32_t ti = 0xFFFFFFFFu, oi = 0xFFFFFFFFu;
   if (ref != REF_NONE) {
@@ -996,14 +1165,56 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
 }  // namespace
 
 // ---- launchers ------------------------------------------------------------------------
-void launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters, int parity,
-                   WorkCounters* work, uint32_t* queues, bool count_work, int grid, hipStream_t stream) {
-  if (count_work)
-    hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, sc, rc, cur, counters, parity, work,
-                       queues);
-  else
-    hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, sc, rc, cur, counters, parity,
-                       work, queues);
+ExtendConfig plan_extend(const DeviceScene& sc, int num_cu, uint32_t pool) {
+  ExtendConfig cfg{};
+  // a stack entry per inner node on the path plus the pending sibling of the last one
+  const int depth = (int)sc.bvh_height + 2;
+  const size_t node_bytes = (size_t)sc.n_nodes * 64;
+  const size_t lds_total = sizeof(ExtendShared) + node_bytes + (size_t)depth * LDS_BLOCK_THREADS * 4;
+  if (sc.n_nodes != 0 && lds_total <= LDS_BYTES_PER_CU - 1024) {
+    cfg.lds_nodes = true;
+    cfg.block = LDS_BLOCK_THREADS;
+    cfg.stack_depth = depth;
+    cfg.lds_bytes = lds_total;
+    cfg.grid = num_cu;
+  } else {
+    cfg.lds_nodes = false;
+    cfg.block = BLOCK_THREADS;
+    cfg.stack_depth = STACK_DEPTH;
+    cfg.lds_bytes = sizeof(ExtendShared) + (size_t)STACK_DEPTH * BLOCK_THREADS * 4;
+    cfg.grid = num_cu * 5;  // 32 KiB of stack per block: five blocks share a CU's LDS
+  }
+  const int needed = (int)((pool + (uint32_t)cfg.block - 1) / (uint32_t)cfg.block);
+  if (cfg.grid > needed) cfg.grid = needed;
+  if (cfg.grid < 1) cfg.grid = 1;
+  return cfg;
+}
+
+template <bool COUNT, bool LDS_NODES, int THREADS>
+static hipError_t launch_extend_as(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters,
+                                   int parity, WorkCounters* work, uint32_t* queues, const ExtendConfig& cfg,
+                                   hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<COUNT, LDS_NODES, THREADS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_extend<COUNT, LDS_NODES, THREADS>), dim3(cfg.grid), dim3(THREADS), cfg.lds_bytes, stream, sc, rc,
+                     cur, counters, parity, work, queues);
+  return hipGetLastError();
+}
+
+hipError_t launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters, int parity,
+                         WorkCounters* work, uint32_t* queues, bool count_work, const ExtendConfig& cfg,
+                         hipStream_t stream) {
+  if (cfg.lds_nodes) {
+    return count_work ? launch_extend_as<true, true, LDS_BLOCK_THREADS>(sc, rc, cur, counters, parity, work, queues, cfg, stream)
+                      : launch_extend_as<false, true, LDS_BLOCK_THREADS>(sc, rc, cur, counters, parity, work, queues, cfg, stream);
+  }
+  return count_work ? launch_extend_as<true, false, BLOCK_THREADS>(sc, rc, cur, counters, parity, work, queues, cfg, stream)
+                    : launch_extend_as<false, false, BLOCK_THREADS>(sc, rc, cur, counters, parity, work, queues, cfg, stream);
 }
 
 void launch_shade(const DeviceScene& sc, const RenderConst& rc, const float4* cur, float4* next,
@@ -1027,11 +1238,6 @@ void launch_trace(const DeviceScene& sc, const mirt_ray* rays, size_t n, uint32_
                      type_index, object_index, t);
 }
 
-int extend_blocks_per_cu() {
-  int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false>, BLOCK_THREADS, 0) != hipSuccess || n < 1) n = 4;
-  return n > 8 ? 8 : n;
-}
 int shade_blocks_per_cu() {
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, BLOCK_THREADS, 0) != hipSuccess || n < 1) n = 4;

@@ -62,13 +62,12 @@ struct mirt_context {
   DeviceBuffer work;
   DeviceBuffer image_sum;
   DeviceBuffer image_rgb;
-  int extend_blocks = 0;
   int shade_blocks = 0;
 };
 
 struct mirt_scene {
   DeviceBuffer nodes, sphere, msphere, rect, box;
-  DeviceBuffer prim_info[N_PRIM_TAGS], prim_ids[N_PRIM_TAGS];
+  DeviceBuffer prim_ids[N_PRIM_TAGS];
   DeviceBuffer chains, chain_ops, materials, textures, perlin_vec, perlin_perm, images, image_data, lights,
       light_groups, media;
   DeviceScene view{};
@@ -222,8 +221,12 @@ int validate_desc(const mirt_scene_desc& d, std::string& why) {
   return MIRT_OK;
 }
 
-uint4 info_of(const mirt_scene_desc& d, const mirt_prim_header& h) {
-  return make_uint4(make_material_word(d.materials[h.material].kind, h.material), h.chain, h.order, h.flags);
+// info quad of a primitive record, stored as float bit patterns behind the geometry
+float4 info_of(const mirt_scene_desc& d, const mirt_prim_header& h) {
+  const uint32_t w[4] = {make_material_word(d.materials[h.material].kind, h.material), h.chain, h.order, h.flags};
+  float4 f;
+  std::memcpy(&f, w, sizeof(f));
+  return f;
 }
 
 }  // namespace
@@ -256,7 +259,6 @@ int mirt_context_create(int device_id, mirt_context** out) {
     delete ctx;
     return fail(nullptr, MIRT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   }
-  ctx->extend_blocks = extend_blocks_per_cu();
   ctx->shade_blocks = shade_blocks_per_cu();
   *out = ctx;
   return MIRT_OK;
@@ -309,31 +311,29 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     return true;
   };
   std::vector<float4> geo;
-  std::vector<uint4> info;
   std::vector<uint2> ids;
 
-  geo.resize(d.n_spheres); info.resize(d.n_spheres); ids.resize(d.n_spheres);
+  geo.resize((size_t)d.n_spheres * SPHERE_STRIDE); ids.resize(d.n_spheres);
   for (uint32_t i = 0; i < d.n_spheres; ++i) {
     const mirt_sphere& p = d.spheres[i];
-    geo[i] = make_float4(p.center[0], p.center[1], p.center[2], p.radius);
-    info[i] = info_of(d, p.h);
+    geo[SPHERE_STRIDE * (size_t)i] = make_float4(p.center[0], p.center[1], p.center[2], p.radius);
+    geo[SPHERE_STRIDE * (size_t)i + 1] = info_of(d, p.h);
     ids[i] = make_uint2(p.h.type_index, p.h.object_index);
     Bounds b;
     b.add(chain_to_world(d, p.h.chain, P3{p.center[0], p.center[1], p.center[2]}), std::fabs(p.radius));
     if (!push_prim(b, TAG_SPHERE, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sphere with non-finite bounds");
   }
   MIRT_HIP(ctx, upload(s.sphere, geo));
-  MIRT_HIP(ctx, upload(s.prim_info[TAG_SPHERE], info));
   MIRT_HIP(ctx, upload(s.prim_ids[TAG_SPHERE], ids));
 
-  geo.assign((size_t)d.n_moving_spheres * 3, make_float4(0, 0, 0, 0));
-  info.resize(d.n_moving_spheres); ids.resize(d.n_moving_spheres);
+  geo.assign((size_t)d.n_moving_spheres * MSPHERE_STRIDE, make_float4(0, 0, 0, 0));
+  ids.resize(d.n_moving_spheres);
   for (uint32_t i = 0; i < d.n_moving_spheres; ++i) {
     const mirt_moving_sphere& p = d.moving_spheres[i];
-    geo[3 * (size_t)i] = make_float4(p.center0[0], p.center0[1], p.center0[2], p.radius);
-    geo[3 * (size_t)i + 1] = make_float4(p.center1[0], p.center1[1], p.center1[2], p.time0);
-    geo[3 * (size_t)i + 2] = make_float4(p.time1, 0, 0, 0);
-    info[i] = info_of(d, p.h);
+    geo[MSPHERE_STRIDE * (size_t)i] = make_float4(p.center0[0], p.center0[1], p.center0[2], p.radius);
+    geo[MSPHERE_STRIDE * (size_t)i + 1] = make_float4(p.center1[0], p.center1[1], p.center1[2], p.time0);
+    geo[MSPHERE_STRIDE * (size_t)i + 2] = make_float4(p.time1, 0, 0, 0);
+    geo[MSPHERE_STRIDE * (size_t)i + 3] = info_of(d, p.h);
     ids[i] = make_uint2(p.h.type_index, p.h.object_index);
     Bounds b;
     // the centre is linear in time (objects.rs:132-135): bound the two ends of the valid interval
@@ -347,18 +347,17 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     if (!push_prim(b, TAG_MOVING_SPHERE, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "moving sphere with non-finite bounds");
   }
   MIRT_HIP(ctx, upload(s.msphere, geo));
-  MIRT_HIP(ctx, upload(s.prim_info[TAG_MOVING_SPHERE], info));
   MIRT_HIP(ctx, upload(s.prim_ids[TAG_MOVING_SPHERE], ids));
 
-  geo.assign((size_t)d.n_rects * 2, make_float4(0, 0, 0, 0));
-  info.resize(d.n_rects); ids.resize(d.n_rects);
+  geo.assign((size_t)d.n_rects * RECT_STRIDE, make_float4(0, 0, 0, 0));
+  ids.resize(d.n_rects);
   for (uint32_t i = 0; i < d.n_rects; ++i) {
     const mirt_rect& p = d.rects[i];
-    geo[2 * (size_t)i] = make_float4(p.a0, p.a1, p.b0, p.b1);
+    geo[RECT_STRIDE * (size_t)i] = make_float4(p.a0, p.a1, p.b0, p.b1);
     float axis_bits;
     std::memcpy(&axis_bits, &p.axis, 4);
-    geo[2 * (size_t)i + 1] = make_float4(p.k, axis_bits, 0, 0);
-    info[i] = info_of(d, p.h);
+    geo[RECT_STRIDE * (size_t)i + 1] = make_float4(p.k, axis_bits, 0, 0);
+    geo[RECT_STRIDE * (size_t)i + 2] = info_of(d, p.h);
     ids[i] = make_uint2(p.h.type_index, p.h.object_index);
     float mn[3], mx[3];
     if (p.axis == MIRT_RECT_XY) { mn[0] = p.a0; mx[0] = p.a1; mn[1] = p.b0; mx[1] = p.b1; mn[2] = mx[2] = p.k; }
@@ -369,23 +368,21 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     if (!push_prim(b, TAG_RECT, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "rect with non-finite bounds");
   }
   MIRT_HIP(ctx, upload(s.rect, geo));
-  MIRT_HIP(ctx, upload(s.prim_info[TAG_RECT], info));
   MIRT_HIP(ctx, upload(s.prim_ids[TAG_RECT], ids));
 
-  geo.assign((size_t)d.n_boxes * 2, make_float4(0, 0, 0, 0));
-  info.resize(d.n_boxes); ids.resize(d.n_boxes);
+  geo.assign((size_t)d.n_boxes * BOX_STRIDE, make_float4(0, 0, 0, 0));
+  ids.resize(d.n_boxes);
   for (uint32_t i = 0; i < d.n_boxes; ++i) {
     const mirt_box& p = d.boxes[i];
-    geo[2 * (size_t)i] = make_float4(p.min[0], p.min[1], p.min[2], 0);
-    geo[2 * (size_t)i + 1] = make_float4(p.max[0], p.max[1], p.max[2], 0);
-    info[i] = info_of(d, p.h);
+    geo[BOX_STRIDE * (size_t)i] = make_float4(p.min[0], p.min[1], p.min[2], 0);
+    geo[BOX_STRIDE * (size_t)i + 1] = make_float4(p.max[0], p.max[1], p.max[2], 0);
+    geo[BOX_STRIDE * (size_t)i + 2] = info_of(d, p.h);
     ids[i] = make_uint2(p.h.type_index, p.h.object_index);
     Bounds b;
     add_corners(d, p.h.chain, p.min, p.max, b);
     if (!push_prim(b, TAG_BOX, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "box with non-finite bounds");
   }
   MIRT_HIP(ctx, upload(s.box, geo));
-  MIRT_HIP(ctx, upload(s.prim_info[TAG_BOX], info));
   MIRT_HIP(ctx, upload(s.prim_ids[TAG_BOX], ids));
 
   // ---- acceleration structure ----------------------------------------------------
@@ -457,15 +454,13 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   DeviceScene& v = s.view;
   v.nodes = s.nodes.as<float4>();
   v.root_ref = bvh.root_ref;
+  v.n_nodes = (uint32_t)bvh.nodes.size();
+  v.bvh_height = bvh.height;
   v.n_chains = d.n_chains;
   v.sphere = s.sphere.as<float4>();
   v.msphere = s.msphere.as<float4>();
   v.rect = s.rect.as<float4>();
   v.box = s.box.as<float4>();
-  v.info_sphere = s.prim_info[TAG_SPHERE].as<uint4>();
-  v.info_msphere = s.prim_info[TAG_MOVING_SPHERE].as<uint4>();
-  v.info_rect = s.prim_info[TAG_RECT].as<uint4>();
-  v.info_box = s.prim_info[TAG_BOX].as<uint4>();
   v.ids_sphere = s.prim_ids[TAG_SPHERE].as<uint2>();
   v.ids_msphere = s.prim_ids[TAG_MOVING_SPHERE].as<uint2>();
   v.ids_rect = s.prim_ids[TAG_RECT].as<uint2>();
@@ -516,6 +511,9 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   if (p.width < 2 || p.height < 2) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
   if ((uint64_t)p.width * p.height >= (1ull << 31)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "image too large");
   if (p.samples_per_pixel == 0) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be positive");
+  if ((uint64_t)p.first_sample + p.samples_per_pixel - 1 > MAX_SAMPLE_INDEX)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sample index beyond 2^24 - 1");
+  if (p.max_depth > MAX_DEPTH_LIMIT) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "max_depth above 255");
   if (!(camera->time0 <= camera->time1)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera time0 must be <= time1");
   if (scene->has_moving && (camera->time0 < scene->time0 || camera->time1 > scene->time1))
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera shutter interval outside the scene's time range");
@@ -525,10 +523,11 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   if (stats) stats->samples = total;
   if (p.max_depth == 0) return MIRT_OK;  // renderer.rs:147-149: every sample is black
 
-  uint32_t pool = p.path_pool ? p.path_pool : (1u << 21);
-  pool = std::max(pool, 64u * 1024u);
-  pool = (pool + 255u) & ~255u;
-  if ((uint64_t)pool > total) pool = (uint32_t)((total + 255u) & ~255ull);
+  // paths in flight: a whole number of chunks per region, no more than the render has paths
+  uint64_t want = p.path_pool ? p.path_pool : (1u << 21);
+  want = std::min<uint64_t>(want, total);
+  want = std::min<uint64_t>(std::max<uint64_t>(want, POOL_GRANULE), 1u << 27);
+  const uint32_t pool = (uint32_t)((want + POOL_GRANULE - 1) / POOL_GRANULE * POOL_GRANULE);
 
   MIRT_HIP(ctx, ctx->paths[0].ensure((size_t)pool * 64));
   MIRT_HIP(ctx, ctx->paths[1].ensure((size_t)pool * 64));
@@ -548,11 +547,12 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   rc.key0 = (uint32_t)p.seed;
   rc.key1 = (uint32_t)(p.seed >> 32);
   rc.pool = pool;
+  rc.region_cap = pool / N_REGIONS;
   rc.total_paths = total;
 
   const bool count_work = (p.flags & MIRT_RENDER_COUNT_WORK) != 0;
   const bool time_kernels = (p.flags & MIRT_RENDER_TIME_KERNELS) != 0;
-  const int extend_grid = std::max(1, std::min(ctx->num_cu * ctx->extend_blocks, (int)((pool + 255u) / 256u)));
+  const ExtendConfig extend_cfg = plan_extend(scene->view, ctx->num_cu, pool);
   const int shade_grid = std::max(1, std::min(ctx->num_cu * ctx->shade_blocks, (int)((pool + 255u) / 256u)));
 
   std::vector<hipEvent_t> events;  // start/stop pairs: extend, shade, extend, shade, ...
@@ -582,8 +582,8 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
     burst = std::max<uint64_t>(1, std::min<uint64_t>(burst, 256));
     for (uint64_t b = 0; b < burst; ++b) {
       if (time_kernels) MIRT_HIP(ctx, stamp());
-      launch_extend(scene->view, rc, cur, counters, parity, ctx->work.as<WorkCounters>(), queues, count_work,
-                    extend_grid, stream);
+      MIRT_HIP(ctx, launch_extend(scene->view, rc, cur, counters, parity, ctx->work.as<WorkCounters>(), queues,
+                                  count_work, extend_cfg, stream));
       if (time_kernels) { MIRT_HIP(ctx, stamp()); MIRT_HIP(ctx, stamp()); }
       launch_shade(scene->view, rc, cur, next, counters, parity, queues, rgb_sum_device, shade_grid, stream);
       if (time_kernels) MIRT_HIP(ctx, stamp());
@@ -596,7 +596,9 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
     MIRT_HIP(ctx, hipMemcpyAsync(&h, counters + parity, sizeof(h), hipMemcpyDeviceToHost, stream));
     MIRT_HIP(ctx, hipStreamSynchronize(stream));
     issued_seen = h.issued;
-    if (issued_seen >= total && h.n_cur == 0) break;
+    uint64_t alive = 0;
+    for (uint32_t r = 0; r < N_REGIONS; ++r) alive += h.region[r].n_cur;
+    if (issued_seen >= total && alive == 0) break;
     if (iterations > 100000000u) return fail(ctx, MIRT_ERR_DEVICE, "render did not converge");
   }
   const auto t_end = std::chrono::steady_clock::now();
@@ -610,6 +612,7 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
       stats->segments = w.segments;
       stats->nodes_visited = w.nodes;
       stats->prims_tested = w.prims;
+      for (int k = 0; k < MIRT_PHASE_COUNT; ++k) stats->extend_phase_cycles[k] = w.cycles[k];
     }
     if (time_kernels) {
       for (size_t i = 0; i + 3 < events.size(); i += 4) {

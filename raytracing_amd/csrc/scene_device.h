@@ -27,9 +27,11 @@ __host__ __device__ inline uint32_t ref_index(uint32_t ref) { return ref & 0x0FF
 __host__ __device__ inline uint32_t make_material_word(uint32_t kind, uint32_t index) { return (kind << 28) | index; }
 
 // Traversal stack entries per lane (kept in LDS).  The host builder never
-// produces a tree deeper than this.
+// produces a tree taller than STACK_DEPTH - 2.
 constexpr int STACK_DEPTH = 32;
-constexpr int BLOCK_THREADS = 256;
+constexpr int BLOCK_THREADS = 256;       // shade, trace, and extend with the BVH in global memory
+constexpr int LDS_BLOCK_THREADS = 1024;  // extend with the BVH staged in LDS: one block per CU
+constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
 // BVH node, 64 bytes = 4 x float4:
 //   n0 = left.min.xyz,  bits(left ref)
@@ -38,9 +40,15 @@ constexpr int BLOCK_THREADS = 256;
 //   n3 = right.max.xyz, unused
 // Child boxes live in the parent so one 64-byte fetch decides both children.
 
-// Per-primitive side data (one uint4 per primitive, per tag).
-//   x = material word, y = chain index, z = order (tie-break rank), w = flags
-// ids: uint2 (type_index, object_index) per primitive, per tag.
+// Primitive records: geometry float4s followed by one info word quad
+//   info = bits(material word), bits(chain index), bits(order = tie-break rank), bits(flags)
+// so that one cache line holds everything a primitive test needs.
+//   sphere         2 x float4: (center, radius) info
+//   moving sphere  4 x float4: (c0, radius) (c1, time0) (time1,-,-,-) info
+//   rect           3 x float4: (a0,a1,b0,b1) (k, bits(axis), -, -) info
+//   box            3 x float4: (min,-) (max,-) info
+// ids: uint2 (type_index, object_index) per primitive, per tag (only read when ids are reported).
+constexpr uint32_t SPHERE_STRIDE = 2, MSPHERE_STRIDE = 4, RECT_STRIDE = 3, BOX_STRIDE = 3;
 
 struct DMaterial {  // 16 B
   uint32_t kind;
@@ -86,16 +94,15 @@ struct DeviceScene {
   uint32_t root_ref;
   uint32_t n_chains;  // 1 = only the empty chain: skip chain lookups entirely
 
-  const float4* sphere;   // 1 float4 per sphere: center, radius
-  const float4* msphere;  // 3 per moving sphere: (c0, radius) (c1, time0) (time1,-,-,-)
-  const float4* rect;     // 2 per rect: (a0,a1,b0,b1) (k, bits(axis), -, -)
-  const float4* box;      // 2 per box: (min,-) (max,-)
+  uint32_t n_nodes;
+  uint32_t bvh_height;  // inner nodes on the longest root-to-leaf path
+
+  const float4* sphere;   // primitive records, layout above
+  const float4* msphere;
+  const float4* rect;
+  const float4* box;
   // per tag (sphere, moving sphere, rect, box); separate members rather than
   // an array so a run-time tag selects a pointer without a private-memory copy
-  const uint4* info_sphere;
-  const uint4* info_msphere;
-  const uint4* info_rect;
-  const uint4* info_box;
   const uint2* ids_sphere;
   const uint2* ids_msphere;
   const uint2* ids_rect;
@@ -121,13 +128,35 @@ struct DeviceScene {
   const uint2* light_groups;  // (first_light, n_lights)
 };
 
-// Per-iteration counters, double buffered by iteration parity.
+// ---- the path pool ----------------------------------------------------------------
+// The pool is split into N_REGIONS regions so that no counter is shared by the
+// whole GPU: slots are dealt to regions in chunks of REGION_CHUNK (chunk c belongs
+// to region c % N_REGIONS), each region compacts its own survivors and owns four
+// material queues.  A wave always works on 64 consecutive slots of one chunk, so
+// every reservation it makes goes to one region's counters.
+constexpr uint32_t N_REGIONS = 64;
+constexpr uint32_t REGION_CHUNK = 1024;
+constexpr uint32_t POOL_GRANULE = N_REGIONS * REGION_CHUNK;
+
+__host__ __device__ inline uint32_t slot_region(uint32_t slot) { return (slot / REGION_CHUNK) % N_REGIONS; }
+__host__ __device__ inline uint32_t slot_local(uint32_t slot) {
+  return (slot / (REGION_CHUNK * N_REGIONS)) * REGION_CHUNK + (slot % REGION_CHUNK);
+}
+__host__ __device__ inline uint32_t region_slot(uint32_t region, uint32_t local) {
+  return ((local / REGION_CHUNK) * N_REGIONS + region) * REGION_CHUNK + (local % REGION_CHUNK);
+}
+
+// Per-iteration counters, double buffered by iteration parity; one 128-byte block per region.
+struct RegionCounters {
+  uint32_t n_cur;       // paths the region carries over from the previous iteration (filled by shade)
+  uint32_t pad0[3];
+  uint32_t queue_n[4];  // entries in the region's material queues (filled by extend)
+  uint32_t pad1[24];
+};
 struct IterCounters {
-  uint32_t n_cur;        // paths carried over from the previous iteration (filled by shade)
-  uint32_t queue_n[4];   // entries in each material queue (filled by extend)
-  uint32_t pad[3];
-  uint64_t issued;       // camera paths started before this iteration
-  uint64_t pad2;
+  uint64_t issued;  // camera paths started before this iteration
+  uint64_t pad[15];
+  RegionCounters region[N_REGIONS];
 };
 
 struct WorkCounters {
@@ -135,6 +164,9 @@ struct WorkCounters {
   unsigned long long nodes;
   unsigned long long prims;
   unsigned long long pad;
+  // shader-clock cycles summed over waves, per phase of extend (instrumented build only):
+  // 0 load/generate, 1 inner-node loop, 2 primitive tests, 3 media, 4 write-back + binning, 5 whole kernel
+  unsigned long long cycles[MIRT_PHASE_COUNT];
 };
 
 constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3, N_QUEUES = 4;
@@ -146,26 +178,40 @@ struct RenderConst {
   uint32_t max_depth;
   float background[3];
   uint32_t key0, key1;
-  uint32_t pool;             // path records per buffer
+  uint32_t pool;             // path records per buffer = N_REGIONS * region_cap
+  uint32_t region_cap;       // slots per region, a multiple of REGION_CHUNK
   uint64_t total_paths;      // width*height*samples_per_pixel of this call
 };
 
 // Path record, 64 bytes = 4 x float4:
 //   r0 = origin.xyz, time
-//   r1 = direction.xyz, t of the closest hit (written by extend)
-//   r2 = throughput.rgb, bits(pixel = y*width + x, y up)
-//   r3 = bits(sample index), bits(bounce), bits(hit ref), unused
+//   r1 = direction.xyz, bits(pixel = y*width + x, y up)
+//   r2 = throughput.rgb, bits(sample index << 8 | bounce)
+//   r3 = t of the closest hit, bits(hit ref), -, -     (the only part extend writes for a surviving path)
+// Material queue q of region s holds slot numbers at queues[(q * N_REGIONS + s) * region_cap ...].
+constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
+constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
 // ---- launchers implemented in kernels.hip ------------------------------------
-void launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters, int parity,
-                   WorkCounters* work, uint32_t* queues, bool count_work, int grid, hipStream_t stream);
+// How extend is launched for a scene: with the whole BVH staged in LDS when
+// it fits beside the traversal stacks of a 1024-thread block, else from global memory.
+struct ExtendConfig {
+  bool lds_nodes;
+  int block;
+  int grid;
+  int stack_depth;
+  size_t lds_bytes;
+};
+ExtendConfig plan_extend(const DeviceScene& sc, int num_cu, uint32_t pool);
+hipError_t launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters, int parity,
+                         WorkCounters* work, uint32_t* queues, bool count_work, const ExtendConfig& cfg,
+                         hipStream_t stream);
 void launch_shade(const DeviceScene& sc, const RenderConst& rc, const float4* cur, float4* next,
                   IterCounters* counters, int parity, const uint32_t* queues, float* rgb_sum, int grid,
                   hipStream_t stream);
 void launch_resolve(const float* rgb_sum, uint32_t n_values, uint32_t spp, uint8_t* rgb24, hipStream_t stream);
 void launch_trace(const DeviceScene& sc, const mirt_ray* rays, size_t n, uint32_t key0, uint32_t key1,
                   uint32_t* type_index, uint32_t* object_index, float* t, hipStream_t stream);
-int extend_blocks_per_cu();
 int shade_blocks_per_cu();
 
 }  // namespace mirt

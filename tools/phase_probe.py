@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Prints where the waves of the extend kernel spend their cycles (instrumented build, MIRT_RENDER_COUNT_WORK)."""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import raytracing_amd as R
+
+name = sys.argv[1] if len(sys.argv) > 1 else "final_scene"
+w, h, spp = (1920, 1080, 8)
+g = R.ExampleScene(name)
+g.render(w, h, 2, aspect=w / h)
+_, _, st = g.render(w, h, spp, aspect=w / h, flags=R.MIRT_RENDER_COUNT_WORK | R.MIRT_RENDER_TIME_KERNELS)
+c = st["extend_phase_cycles"]
+names = ["load/generate", "inner nodes", "primitive tests", "media", "write+bin", "total"]
+seg = st["segments"]
+print(f"{name}: segments {seg} nodes/seg {st['nodes_visited']/seg:.2f} prims/seg {st['prims_tested']/seg:.2f} "
+      f"iters {st['iterations']} extend ms {st['kernel_ms'][0]:.2f} shade ms {st['kernel_ms'][1]:.2f}")
+for n, v in zip(names, c):
+    print(f"  {n:16s} {v/1e9:9.3f} Gcycles  {100*v/max(1,c[5]):5.1f} %   {v/seg*64:8.1f} cycles per 64 segments")
