@@ -48,32 +48,36 @@ uint32_t ceil_log2(size_t n) {
 struct Builder {
   std::vector<BuildPrim>& prims;
   std::vector<HostNode>& nodes;
+  uint32_t leaf_max;
+
+  Child make_leaf(size_t lo, size_t hi) const {
+    Child c;
+    c.ref = 0x80000000u | ((uint32_t)(hi - lo - 1) << 28) | (uint32_t)lo;
+    c.box.reset();
+    for (size_t i = lo; i < hi; ++i) c.box.grow(prims[i].mn, prims[i].mx);
+    c.height = 0;
+    return c;
+  }
 
   float centroid(const BuildPrim& p, int axis) const { return 0.5f * (p.mn[axis] + p.mx[axis]); }
 
   Child build(size_t lo, size_t hi, uint32_t budget) {
-    if (hi - lo == 1) {
-      Child c;
-      c.ref = prims[lo].ref;
-      c.box.reset();
-      c.box.grow(prims[lo].mn, prims[lo].mx);
-      c.height = 0;
-      return c;
-    }
+    if (hi - lo == 1) return make_leaf(lo, hi);
     const size_t n = hi - lo;
-    const uint32_t node_index = (uint32_t)nodes.size();
-    nodes.emplace_back();
 
     Box cb;  // centroid bounds
+    Box all;
     cb.reset();
+    all.reset();
     for (size_t i = lo; i < hi; ++i) {
       const float c[3] = {centroid(prims[i], 0), centroid(prims[i], 1), centroid(prims[i], 2)};
       cb.grow(c, c);
+      all.grow(prims[i].mn, prims[i].mx);
     }
     size_t mid = lo + n / 2;
     const bool force_median = ceil_log2(n) + 1 >= budget;
     bool split_done = false;
-    if (!force_median && n > 2) {
+    if (!force_median && n >= 2) {
       // binned SAH over the three axes
       float best_cost = std::numeric_limits<float>::infinity();
       int best_axis = -1, best_bin = -1;
@@ -111,6 +115,10 @@ struct Builder {
           if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
         }
       }
+      // a small group stays one leaf when splitting it would not pay: one more node step against the
+      // primitive tests the children's smaller boxes would save (a node step costs about one test)
+      if (n <= leaf_max && best_axis >= 0 && !(best_cost / std::max(all.half_area(), 1e-30f) + 1.0f < (float)n))
+        return make_leaf(lo, hi);
       if (best_axis >= 0) {
         const float extent = cb.mx[best_axis] - cb.mn[best_axis];
         const float scale = (float)kBins / extent;
@@ -124,6 +132,7 @@ struct Builder {
         split_done = mid > lo && mid < hi;
       }
     }
+    if (!split_done && n <= leaf_max) return make_leaf(lo, hi);  // nothing separates them
     if (!split_done) {
       // balanced split along the widest centroid axis
       int axis = 0;
@@ -136,6 +145,8 @@ struct Builder {
       std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
                        [&](const BuildPrim& a, const BuildPrim& b) { return centroid(a, axis) < centroid(b, axis); });
     }
+    const uint32_t node_index = (uint32_t)nodes.size();
+    nodes.emplace_back();
     const Child l = build(lo, mid, budget - 1);
     const Child r = build(mid, hi, budget - 1);
     HostNode& nd = nodes[node_index];
@@ -158,11 +169,11 @@ struct Builder {
 
 }  // namespace
 
-BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height) {
+BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t leaf_max) {
   BuiltBvh out;
   if (prims.empty()) return out;
   out.nodes.reserve(prims.size());
-  Builder b{prims, out.nodes};
+  Builder b{prims, out.nodes, std::max(1u, std::min(leaf_max, 8u))};
   const Child root = b.build(0, prims.size(), max_height + 1);
   out.root_ref = root.ref;
   out.height = root.height;

@@ -11,7 +11,7 @@ namespace mirt {
 struct BuildPrim {
   float mn[3];
   float mx[3];
-  uint32_t ref;  // leaf reference stored in the tree
+  uint32_t id;  // caller's primitive id; the build permutes the array into tree order
 };
 
 struct HostNode {  // 64 bytes, layout documented in scene_device.h
@@ -34,9 +34,11 @@ struct BuiltBvh {
   float mx[3] = {0, 0, 0};
 };
 
+// Leaves hold up to `leaf_max` (<= 8) primitives that are consecutive in the permuted `prims`
+// array: a leaf reference is 0x80000000 | (count - 1) << 28 | index of its first primitive.
 // max_height: the traversal stack holds one entry per inner node on the
 // current path, so the tree is kept no taller than this (falls back to
 // balanced median splits when the budget gets tight).
-BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height);
+BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t leaf_max);
 
 }  // namespace mirt

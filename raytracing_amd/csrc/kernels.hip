@@ -16,6 +16,8 @@
 // add is harmless (the conservative box test) it is written explicitly.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "scene_device.h"
 
 namespace mirt {
@@ -113,31 +115,25 @@ __device__ __forceinline__ float rng_range(Rng& r, float lo, float hi) { return 
 __device__ __forceinline__ uint4 as_uint4(float4 f) {
   return make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
 }
-// info quad of a primitive record: material word, chain, order, flags
-__device__ __forceinline__ uint4 prim_info(const DeviceScene& sc, uint32_t ref) {
-  const uint32_t tag = ref_tag(ref), idx = ref_index(ref);
-  float4 f;
-  if (tag == TAG_SPHERE) f = sc.sphere[SPHERE_STRIDE * (size_t)idx + 1];
-  else if (tag == TAG_MOVING_SPHERE) f = sc.msphere[MSPHERE_STRIDE * (size_t)idx + 3];
-  else if (tag == TAG_RECT) f = sc.rect[RECT_STRIDE * (size_t)idx + 2];
-  else f = sc.box[BOX_STRIDE * (size_t)idx + 2];
-  return as_uint4(f);
+// Where the traversal reads nodes, primitive records and wrapper chains from: the block's LDS copies
+// or global memory.  PSTRIDE (template parameter of the users) is the record stride in float4s.
+struct SceneTables {
+  const float4* nodes;
+  const float4* prims;
+  const uint2* chains;
+  const float4* chain_ops;
+};
+__device__ __forceinline__ SceneTables global_tables(const DeviceScene& sc) {
+  return SceneTables{sc.nodes, sc.prims, sc.chains, sc.chain_ops};
 }
-__device__ __forceinline__ uint2 prim_ids(const DeviceScene& sc, uint32_t ref) {
-  const uint32_t tag = ref_tag(ref);
-  const uint2* p = tag == TAG_SPHERE ? sc.ids_sphere
-                   : tag == TAG_MOVING_SPHERE ? sc.ids_msphere
-                   : tag == TAG_RECT ? sc.ids_rect
-                                     : sc.ids_box;
-  return p[ref_index(ref)];
-}
+__device__ __forceinline__ uint2 prim_ids(const DeviceScene& sc, uint32_t ref) { return sc.prim_ids[ref_index(ref)]; }
 
 // ---- wrappers (transforms.rs) --------------------------------------------------
 // Applies the wrappers of a chain to a ray, outermost first (transforms.rs:16, 82-91).
-__device__ __forceinline__ Ray chain_forward(const DeviceScene& sc, uint32_t chain, Ray r) {
-  const uint2 c = sc.chains[chain];
+__device__ __forceinline__ Ray chain_forward(const SceneTables& tb, uint32_t chain, Ray r) {
+  const uint2 c = tb.chains[chain];
   for (uint32_t k = 0; k < c.y; ++k) {
-    const float4 op = sc.chain_ops[c.x + k];
+    const float4 op = tb.chain_ops[c.x + k];
     const uint32_t kind = __float_as_uint(op.x);
     if (kind == MIRT_OP_TRANSLATE) {
       r.o = r.o - v3(op.y, op.z, op.w);
@@ -175,9 +171,9 @@ __device__ __forceinline__ bool sphere_t(V3 center, float radius, const Ray& r, 
   return true;
 }
 
-__device__ __forceinline__ V3 moving_center(float4 m0, float4 m1, float4 m2, float time) {  // objects.rs:132-135
-  const V3 c0 = xyz(m0), c1 = xyz(m1);
-  const float time0 = m1.w, time1 = m2.x;
+__device__ __forceinline__ V3 moving_center(float4 qa, float4 qb, float time1, float time) {  // objects.rs:132-135
+  const V3 c0 = xyz(qa), c1 = xyz(qb);
+  const float time0 = qb.w;
   return c0 + ((time - time0) / (time1 - time0)) * (c1 - c0);
 }
 
@@ -220,41 +216,35 @@ __device__ __forceinline__ bool box_t(V3 mn, V3 mx, const Ray& r, float t_min, f
   return any;
 }
 
-// t of primitive `ref` for the world-space ray r.  The info quad of the record
-// shares a cache line with the geometry, so looking up the wrapper chain costs
-// no second round trip; the ray goes through the chain in front of the test.
-// `info` receives the record's info quad (material word, chain, order, flags).
-__device__ __forceinline__ bool prim_t(const DeviceScene& sc, uint32_t ref, const Ray& r, float t_min, float t_max,
-                                       float& t, uint4& info) {
-  const uint32_t tag = ref_tag(ref), idx = ref_index(ref);
+// Tests the primitive whose record is number `index` against the world-space ray r: the ray goes
+// through the record's wrapper chain, then through the kind's own test.  Outputs the kind and, for
+// the caller's bookkeeping, the record's order rank and material word.
+template <int PSTRIDE>
+__device__ __forceinline__ bool record_t(const SceneTables& tb, uint32_t index, const Ray& r, float t_min, float t_max,
+                                         float& t, uint32_t& tag, uint32_t& order, uint32_t& material) {
+  const float4* p = tb.prims + PSTRIDE * (size_t)index;
+  const float4 qa = p[0], qc = p[2];
+  const uint32_t chain_tag = __float_as_uint(qc.x);
+  tag = chain_tag & 3u;
+  order = __float_as_uint(qc.y);
+  material = __float_as_uint(qc.z);
+  const uint32_t chain = chain_tag >> 2;
   if (tag == TAG_SPHERE) {
-    const float4* p = sc.sphere + SPHERE_STRIDE * (size_t)idx;
-    const float4 g = p[0];
-    info = as_uint4(p[1]);
-    if (info.y != 0) return sphere_t(xyz(g), g.w, chain_forward(sc, info.y, r), t_min, t_max, t);
-    return sphere_t(xyz(g), g.w, r, t_min, t_max, t);
-  } else if (tag == TAG_MOVING_SPHERE) {
-    const float4* p = sc.msphere + MSPHERE_STRIDE * (size_t)idx;
-    const float4 m0 = p[0], m1 = p[1], m2 = p[2];
-    info = as_uint4(p[3]);
-    const Ray lr = info.y != 0 ? chain_forward(sc, info.y, r) : r;
-    return sphere_t(moving_center(m0, m1, m2, lr.time), m0.w, lr, t_min, t_max, t);
+    if (chain != 0) return sphere_t(xyz(qa), qa.w, chain_forward(tb, chain, r), t_min, t_max, t);
+    return sphere_t(xyz(qa), qa.w, r, t_min, t_max, t);
+  }
+  const float4 qb = p[1];
+  const Ray lr = chain != 0 ? chain_forward(tb, chain, r) : r;
+  if (tag == TAG_MOVING_SPHERE) {
+    return sphere_t(moving_center(qa, qb, qc.w, lr.time), qa.w, lr, t_min, t_max, t);
   } else if (tag == TAG_RECT) {
-    const float4* p = sc.rect + RECT_STRIDE * (size_t)idx;
-    const float4 g0 = p[0], g1 = p[1];
-    info = as_uint4(p[2]);
-    const Ray lr = info.y != 0 ? chain_forward(sc, info.y, r) : r;
     float pa, pb;
-    const bool ok = rect_t(__float_as_uint(g1.y), g0.x, g0.y, g0.z, g0.w, g1.x, lr, t_min, t_max, t, pa, pb);
+    const bool ok = rect_t(__float_as_uint(qb.y), qa.x, qa.y, qa.z, qa.w, qb.x, lr, t_min, t_max, t, pa, pb);
     return ok && !(t != t);
   } else {
-    const float4* p = sc.box + BOX_STRIDE * (size_t)idx;
-    const float4 g0 = p[0], g1 = p[1];
-    info = as_uint4(p[2]);
-    const Ray lr = info.y != 0 ? chain_forward(sc, info.y, r) : r;
     int face;
     float pa, pb;
-    return box_t(xyz(g0), xyz(g1), lr, t_min, t_max, t, face, pa, pb);
+    return box_t(xyz(qa), xyz(qb), lr, t_min, t_max, t, face, pa, pb);
   }
 }
 
@@ -280,21 +270,37 @@ struct Work {
   long long cycles[MIRT_PHASE_COUNT];
 };
 
+// How tree references are coded while walking.  The LDS copy of a small scene recodes them into 16 bits
+// (leaf bit 15, count - 1 in bits 12..14, first record in bits 0..11) so a stack entry is half the size.
+template <bool COMPACT>
+struct RefCode {
+  static constexpr uint32_t LEAF = COMPACT ? 0x8000u : REF_LEAF;
+  static constexpr uint32_t SHIFT = COMPACT ? 12u : 28u;
+  static constexpr uint32_t MASK = COMPACT ? 0x0FFFu : 0x0FFFFFFFu;
+  static constexpr uint32_t NONE = COMPACT ? 0xFFFFu : REF_NONE;
+  static __device__ __forceinline__ uint32_t encode(uint32_t ref) {
+    if (!COMPACT || !(ref & REF_LEAF)) return ref;
+    return ref == REF_NONE ? NONE : (LEAF | (((ref >> 28) & 7u) << SHIFT) | (ref & MASK));
+  }
+};
+constexpr uint32_t COMPACT_MAX_PRIMS = 4096, COMPACT_MAX_NODES = 32768;
+
 // Closest surface over (t_min, inf): the result of the reference's exhaustive
 // scan -- smallest t, and of equal t the primitive with the higher `order`.
-// `nodes` is the node array (in LDS or in global memory, the caller decides);
-// `stack` is this lane's column of an LDS stack whose rows are `stride` words apart.
+// `stack` is this lane's column of an LDS stack whose rows are `stride` entries apart.
 // Two nested loops: a lane walks inner nodes until it holds a leaf, the wave
-// then tests the leaves its lanes hold together.
-template <bool COUNT>
-__device__ __forceinline__ void closest_surface(const DeviceScene& sc, const float4* nodes, const Ray& r, float t_min,
-                                                uint32_t* stack, uint32_t stride, uint32_t& best_ref, float& best_t,
-                                                uint32_t& best_material, Work& work) {
-  best_ref = REF_NONE;
+// then tests the primitives of the leaves its lanes hold together.
+template <bool COUNT, int PSTRIDE, bool COMPACT, class Slot>
+__device__ __forceinline__ void closest_surface(const SceneTables& tb, uint32_t root, const Ray& r,
+                                                float t_min, Slot* stack, uint32_t stride, uint32_t& best_ref,
+                                                float& best_t, uint32_t& best_material, Work& work) {
+  using RC = RefCode<COMPACT>;
+  constexpr uint32_t REF_LEAF = RC::LEAF, REF_NONE = RC::NONE;  // shadow the 32-bit codes inside the walk
+  best_ref = mirt::REF_NONE;
   best_t = kInf;
   best_material = 0;
   uint32_t best_order = 0;
-  uint32_t cur = sc.root_ref;  // REF_NONE (a leaf-tagged sentinel) doubles as "no work left"
+  uint32_t cur = root;  // REF_NONE (leaf bit set) doubles as "no work left"
   if (cur == REF_NONE) return;
   const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
   uint32_t sp = 0;
@@ -303,7 +309,7 @@ __device__ __forceinline__ void closest_surface(const DeviceScene& sc, const flo
     if (COUNT) t0 = clock64();
     while (!(cur & REF_LEAF)) {
       if (COUNT) ++work.nodes;
-      const float4* n = nodes + 4 * (size_t)cur;
+      const float4* n = tb.nodes + 4 * (size_t)cur;
       const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
       float tl, tr;
       const bool hl = slab(xyz(n0), xyz(n1), r.o, inv, t_min, best_t, tl);
@@ -311,7 +317,7 @@ __device__ __forceinline__ void closest_surface(const DeviceScene& sc, const flo
       const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
       if (hl && hr) {
         const bool left_first = tl <= tr;
-        stack[(sp++) * stride] = left_first ? right : left;
+        stack[(sp++) * stride] = (Slot)(left_first ? right : left);
         cur = left_first ? left : right;
       } else if (hl) {
         cur = left;
@@ -323,13 +329,16 @@ __device__ __forceinline__ void closest_surface(const DeviceScene& sc, const flo
     }
     if (COUNT) { t1 = clock64(); work.cycles[MIRT_PHASE_NODES] += t1 - t0; }
     if (cur == REF_NONE) break;
-    float t;
-    uint4 info;
-    if (COUNT) ++work.prims;
-    if (prim_t(sc, cur, r, t_min, best_t, t, info)) {
-      // t == best_t: the later one in the reference's visiting order wins
-      if (t < best_t || best_ref == REF_NONE || info.z > best_order) {
-        best_t = t; best_ref = cur; best_material = info.x; best_order = info.z;
+    const uint32_t first = cur & RC::MASK, last = first + ((cur >> RC::SHIFT) & 7u);
+    for (uint32_t index = first; index <= last; ++index) {
+      float t;
+      uint32_t tag, order, material;
+      if (COUNT) ++work.prims;
+      if (record_t<PSTRIDE>(tb, index, r, t_min, best_t, t, tag, order, material)) {
+        // t == best_t: the later one in the reference's visiting order wins
+        if (t < best_t || best_ref == mirt::REF_NONE || order > best_order) {
+          best_t = t; best_ref = make_leaf(tag, index); best_material = material; best_order = order;
+        }
       }
     }
     cur = sp ? stack[(--sp) * stride] : REF_NONE;
@@ -370,9 +379,9 @@ __device__ __forceinline__ void stage_media(const DeviceScene& sc, MediumEntry* 
     e.boundary_ref = med.boundary_ref;
     e.boundary_chain = 0;
     if (ref_tag(med.boundary_ref) == TAG_SPHERE) {
-      const float4* p = sc.sphere + SPHERE_STRIDE * (size_t)ref_index(med.boundary_ref);
+      const float4* p = sc.prims + PRIM_QUADS * (size_t)ref_index(med.boundary_ref);
       e.boundary = p[0];
-      e.boundary_chain = __float_as_uint(p[1].y);
+      e.boundary_chain = __float_as_uint(p[2].x) >> 2;
     }
     e.chain = med.chain;
     e.material_word = med.material_word;
@@ -386,8 +395,8 @@ __device__ __forceinline__ void stage_media(const DeviceScene& sc, MediumEntry* 
 // Medium m reads draw m of the STAGE_MEDIA stream, so the order media are
 // visited in does not matter; an accepted medium hit replaces the current
 // closest hit exactly as World::hit does with its shrinking t_max.
-__device__ __forceinline__ void closest_media(const DeviceScene& sc, const MediumEntry* table, const Ray& r,
-                                              float t_min, Rng& rng, uint32_t& best_ref, float& best_t,
+__device__ __forceinline__ void closest_media(const DeviceScene& sc, const SceneTables& tb, const MediumEntry* table,
+                                              const Ray& r, float t_min, Rng& rng, uint32_t& best_ref, float& best_t,
                                               uint32_t& best_material) {
   for (uint32_t m = 0; m < sc.n_media; ++m) {
     const MediumEntry med = table[m];
@@ -395,7 +404,7 @@ __device__ __forceinline__ void closest_media(const DeviceScene& sc, const Mediu
     if (ref_tag(med.boundary_ref) == TAG_SPHERE) {
       // The reference intersects the boundary twice, over (-inf, inf) and over (h1 + 0.0001, inf); both
       // calls solve the same quadratic, so the roots are computed once and picked as Sphere::hit would.
-      const Ray lr = med.boundary_chain != 0 ? chain_forward(sc, med.boundary_chain, r) : r;
+      const Ray lr = med.boundary_chain != 0 ? chain_forward(tb, med.boundary_chain, r) : r;
       float r1, r2;
       if (!sphere_roots(xyz(med.boundary), med.boundary.w, lr, r1, r2)) continue;
       if (in_range(r1, -kInf, kInf)) h1 = r1;
@@ -406,15 +415,17 @@ __device__ __forceinline__ void closest_media(const DeviceScene& sc, const Mediu
       else if (in_range(r2, t2_min, kInf)) h2 = r2;
       else continue;
     } else {
-      uint4 info;
-      if (!prim_t(sc, med.boundary_ref, r, -kInf, kInf, h1, info)) continue;
-      if (!prim_t(sc, med.boundary_ref, r, h1 + 0.0001f, kInf, h2, info)) continue;
+      // boundary-only records are not staged in LDS: read them from global memory
+      const SceneTables gt = global_tables(sc);
+      uint32_t tag, order, material;
+      if (!record_t<PRIM_QUADS>(gt, ref_index(med.boundary_ref), r, -kInf, kInf, h1, tag, order, material)) continue;
+      if (!record_t<PRIM_QUADS>(gt, ref_index(med.boundary_ref), r, h1 + 0.0001f, kInf, h2, tag, order, material)) continue;
     }
     if (h1 < t_min) h1 = t_min;
     if (h2 > best_t) h2 = best_t;
     if (h1 >= h2) continue;
     if (h1 < 0.0f) h1 = 0.0f;
-    const Ray mr = med.chain != 0 ? chain_forward(sc, med.chain, r) : r;
+    const Ray mr = med.chain != 0 ? chain_forward(tb, med.chain, r) : r;
     const float ray_length = len(mr.d);
     const float dist_inside = (h2 - h1) * ray_length;
     const float hit_distance = med.neg_inv_density * log2f(rng_at(rng, m));  // log2, as the reference
@@ -473,9 +484,9 @@ __device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, c
     chain = sc.media[idx].chain;
     h.material_word = sc.media[idx].material_word;
   } else {
-    const uint4 info = prim_info(sc, ref);
-    chain = info.y;
-    h.material_word = info.x;
+    const float4 qc = sc.prims[PRIM_QUADS * (size_t)idx + 2];
+    chain = __float_as_uint(qc.x) >> 2;
+    h.material_word = __float_as_uint(qc.z);
   }
   // directions seen by each wrapper (after it transformed the ray)
   V3 dir_at[MIRT_MAX_CHAIN_OPS];
@@ -506,20 +517,20 @@ __device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, c
     h.u = 0.0f; h.v = 0.0f;
     h.front = true;
   } else if (tag == TAG_SPHERE) {
-    const float4 g = sc.sphere[SPHERE_STRIDE * (size_t)idx];
+    const float4 g = sc.prims[PRIM_QUADS * (size_t)idx];
     sphere_record(xyz(g), g.w, r, t_found, h);
   } else if (tag == TAG_MOVING_SPHERE) {
-    const float4* mp = sc.msphere + MSPHERE_STRIDE * (size_t)idx;
-    const float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-    sphere_record(moving_center(m0, m1, m2, r.time), m0.w, r, t_found, h);
+    const float4* mp = sc.prims + PRIM_QUADS * (size_t)idx;
+    const float4 m0 = mp[0], m1 = mp[1];
+    sphere_record(moving_center(m0, m1, mp[2].w, r.time), m0.w, r, t_found, h);
   } else if (tag == TAG_RECT) {
-    const float4 g0 = sc.rect[RECT_STRIDE * (size_t)idx], g1 = sc.rect[RECT_STRIDE * (size_t)idx + 1];
+    const float4 g0 = sc.prims[PRIM_QUADS * (size_t)idx], g1 = sc.prims[PRIM_QUADS * (size_t)idx + 1];
     const uint32_t axis = __float_as_uint(g1.y);
     float t, pa = 0.0f, pb = 0.0f;
     rect_t(axis, g0.x, g0.y, g0.z, g0.w, g1.x, r, kTMin, kInf, t, pa, pb);
     rect_record(axis, g0.x, g0.y, g0.z, g0.w, r, t_found, pa, pb, h);
   } else {
-    const float4 g0 = sc.box[BOX_STRIDE * (size_t)idx], g1 = sc.box[BOX_STRIDE * (size_t)idx + 1];
+    const float4 g0 = sc.prims[PRIM_QUADS * (size_t)idx], g1 = sc.prims[PRIM_QUADS * (size_t)idx + 1];
     const V3 mn = xyz(g0), mx = xyz(g1);
     float t, pa = 0.0f, pb = 0.0f;
     int face = 0;
@@ -800,9 +811,10 @@ struct ExtendShared {
   MediumEntry media[MIRT_MAX_MEDIA];
 };
 
-// LDS_NODES: the block first stages the whole node array in LDS (dynamic shared memory holds
-// [bookkeeping][nodes][stack]); otherwise nodes are fetched from global memory.
-template <bool COUNT, bool LDS_NODES, int THREADS>
+// LDS_SCENE: the block first stages the whole scene the traversal touches in LDS -- dynamic shared memory
+// holds [bookkeeping][nodes][48-byte primitive records][chain ops][chains][stack] -- so the walk never
+// waits on global memory; otherwise those tables are read from global memory and LDS holds the stack only.
+template <bool COUNT, bool LDS_SCENE, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst rc, float4* __restrict__ cur,
                                                     IterCounters* counters, int parity, WorkCounters* work_out,
                                                     uint32_t* __restrict__ queues) {
@@ -810,13 +822,28 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
   static_assert(sizeof(ExtendShared) % 16 == 0, "keeps the node array 16-byte aligned");
   ExtendShared& sh = *reinterpret_cast<ExtendShared*>(smem);
   float4* after = smem + sizeof(ExtendShared) / 16;
-  const float4* nodes = sc.nodes;
-  uint32_t* stack = reinterpret_cast<uint32_t*>(after) + threadIdx.x;
-  if (LDS_NODES) {
-    const uint32_t n4 = sc.n_nodes * 4u;
-    for (uint32_t k = threadIdx.x; k < n4; k += THREADS) after[k] = sc.nodes[k];
-    nodes = after;
-    stack = reinterpret_cast<uint32_t*>(after + n4) + threadIdx.x;
+  SceneTables tb = global_tables(sc);
+  using Slot = typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type;
+  Slot* stack = reinterpret_cast<Slot*>(after) + threadIdx.x;
+  if (LDS_SCENE) {
+    const uint32_t n_node_quads = sc.n_nodes * 4u;
+    const uint32_t n_prim_quads = sc.n_prims * PRIM_QUADS_LDS;
+    float4* l_nodes = after;
+    float4* l_prims = l_nodes + n_node_quads;
+    float4* l_ops = l_prims + n_prim_quads;
+    uint2* l_chains = reinterpret_cast<uint2*>(l_ops + sc.n_chain_ops);
+    for (uint32_t k = threadIdx.x; k < n_node_quads; k += THREADS) {
+      float4 q = sc.nodes[k];
+      if ((k & 3u) < 2u) q.w = __uint_as_float(RefCode<true>::encode(__float_as_uint(q.w)));  // child refs
+      l_nodes[k] = q;
+    }
+    for (uint32_t k = threadIdx.x; k < n_prim_quads; k += THREADS)
+      l_prims[k] = sc.prims[(k / PRIM_QUADS_LDS) * PRIM_QUADS + (k % PRIM_QUADS_LDS)];
+    for (uint32_t k = threadIdx.x; k < sc.n_chain_ops; k += THREADS) l_ops[k] = sc.chain_ops[k];
+    for (uint32_t k = threadIdx.x; k < sc.n_chains; k += THREADS) l_chains[k] = sc.chains[k];
+    tb = SceneTables{l_nodes, l_prims, l_chains, l_ops};
+    // chains are 8 bytes each: round up so the stack starts on a 16-byte boundary
+    stack = reinterpret_cast<Slot*>(l_chains + ((sc.n_chains + 1u) & ~1u)) + threadIdx.x;
   }
 
   IterCounters* c = counters + parity;
@@ -910,11 +937,12 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
     float t = kInf;
     if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_LOAD] += now - ts; ts = now; }
     if (active) {
-      closest_surface<COUNT>(sc, nodes, r, kTMin, stack, THREADS, ref, t, material, work);
+      closest_surface<COUNT, LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS, LDS_SCENE>(
+          tb, RefCode<LDS_SCENE>::encode(sc.root_ref), r, kTMin, stack, THREADS, ref, t, material, work);
       if (COUNT) ts = clock64();
       if (sc.n_media != 0) {
         Rng rng = rng_begin(pixel, sample_bounce >> 8, sample_bounce & 255u, STAGE_MEDIA, rc.key0, rc.key1);
-        closest_media(sc, sh.media, r, kTMin, rng, ref, t, material);
+        closest_media(sc, tb, sh.media, r, kTMin, rng, ref, t, material);
       }
       if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_MEDIA] += now - ts; ts = now; }
       ++segments;
@@ -1142,10 +1170,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
   uint32_t ref, material;
   float t;
   Work work{};
-  closest_surface<false>(sc, sc.nodes, r, kTMin, stack, BLOCK_THREADS, ref, t, material, work);
+  const SceneTables tb = global_tables(sc);
+  closest_surface<false, (int)PRIM_QUADS, false>(tb, sc.root_ref, r, kTMin, stack, BLOCK_THREADS, ref, t, material, work);
   if (sc.n_media != 0) {
     Rng rng = rng_begin((uint32_t)i, 0, 0, STAGE_MEDIA, key0, key1);
-    closest_media(sc, media, r, kTMin, rng, ref, t, material);
+    closest_media(sc, tb, media, r, kTMin, rng, ref, t, material);
   }
   uint32_t ti = 0xFFFFFFFFu, oi = 0xFFFFFFFFu;
   if (ref != REF_NONE) {
@@ -1169,9 +1198,11 @@ ExtendConfig plan_extend(const DeviceScene& sc, int num_cu, uint32_t pool) {
   ExtendConfig cfg{};
   // a stack entry per inner node on the path plus the pending sibling of the last one
   const int depth = (int)sc.bvh_height + 2;
-  const size_t node_bytes = (size_t)sc.n_nodes * 64;
-  const size_t lds_total = sizeof(ExtendShared) + node_bytes + (size_t)depth * LDS_BLOCK_THREADS * 4;
-  if (sc.n_nodes != 0 && lds_total <= LDS_BYTES_PER_CU - 1024) {
+  const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * PRIM_QUADS_LDS * 16 +
+                             (size_t)sc.n_chain_ops * 16 + (size_t)((sc.n_chains + 1u) & ~1u) * 8;
+  // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes
+  const size_t lds_total = sizeof(ExtendShared) + scene_bytes + (size_t)depth * LDS_BLOCK_THREADS * 2;
+  if (lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
     cfg.lds_nodes = true;
     cfg.block = LDS_BLOCK_THREADS;
     cfg.stack_depth = depth;
@@ -1190,18 +1221,18 @@ ExtendConfig plan_extend(const DeviceScene& sc, int num_cu, uint32_t pool) {
   return cfg;
 }
 
-template <bool COUNT, bool LDS_NODES, int THREADS>
+template <bool COUNT, bool LDS_SCENE, int THREADS>
 static hipError_t launch_extend_as(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters,
                                    int parity, WorkCounters* work, uint32_t* queues, const ExtendConfig& cfg,
                                    hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<COUNT, LDS_NODES, THREADS>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<COUNT, LDS_SCENE, THREADS>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_extend<COUNT, LDS_NODES, THREADS>), dim3(cfg.grid), dim3(THREADS), cfg.lds_bytes, stream, sc, rc,
+  hipLaunchKernelGGL((k_extend<COUNT, LDS_SCENE, THREADS>), dim3(cfg.grid), dim3(THREADS), cfg.lds_bytes, stream, sc, rc,
                      cur, counters, parity, work, queues);
   return hipGetLastError();
 }

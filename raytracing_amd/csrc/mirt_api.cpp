@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -66,8 +67,7 @@ struct mirt_context {
 };
 
 struct mirt_scene {
-  DeviceBuffer nodes, sphere, msphere, rect, box;
-  DeviceBuffer prim_ids[N_PRIM_TAGS];
+  DeviceBuffer nodes, prims, prim_ids;
   DeviceBuffer chains, chain_ops, materials, textures, perlin_vec, perlin_perm, images, image_data, lights,
       light_groups, media;
   DeviceScene view{};
@@ -175,8 +175,6 @@ int validate_desc(const mirt_scene_desc& d, std::string& why) {
       if (d.chain_ops[d.chains[i].first_op + k].kind > MIRT_OP_FLIP_FACE) { why = "unknown chain op"; return MIRT_ERR_INVALID_ARGUMENT; }
   }
   if (d.n_media > MIRT_MAX_MEDIA) { why = "more than MIRT_MAX_MEDIA constant media"; return MIRT_ERR_UNSUPPORTED; }
-  if (d.n_spheres >= MAX_PRIMS_PER_TAG || d.n_moving_spheres >= MAX_PRIMS_PER_TAG || d.n_rects >= MAX_PRIMS_PER_TAG ||
-      d.n_boxes >= MAX_PRIMS_PER_TAG) { why = "too many primitives of one kind"; return MIRT_ERR_UNSUPPORTED; }
   for (uint32_t i = 0; i < d.n_spheres; ++i) if (!check_header(d, d.spheres[i].h, why)) return MIRT_ERR_INVALID_ARGUMENT;
   for (uint32_t i = 0; i < d.n_moving_spheres; ++i) if (!check_header(d, d.moving_spheres[i].h, why)) return MIRT_ERR_INVALID_ARGUMENT;
   for (uint32_t i = 0; i < d.n_rects; ++i) {
@@ -219,14 +217,6 @@ int validate_desc(const mirt_scene_desc& d, std::string& why) {
   }
   if (!(d.time0 <= d.time1)) { why = "time0 must be <= time1"; return MIRT_ERR_INVALID_ARGUMENT; }
   return MIRT_OK;
-}
-
-// info quad of a primitive record, stored as float bit patterns behind the geometry
-float4 info_of(const mirt_scene_desc& d, const mirt_prim_header& h) {
-  const uint32_t w[4] = {make_material_word(d.materials[h.material].kind, h.material), h.chain, h.order, h.flags};
-  float4 f;
-  std::memcpy(&f, w, sizeof(f));
-  return f;
 }
 
 }  // namespace
@@ -298,43 +288,45 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   s.has_moving = d.n_moving_spheres != 0;
 
   // ---- geometry + bounds ------------------------------------------------------
+  // Every primitive gets a 4-quad record (layout in scene_device.h) and world-space bounds.  `src` numbers
+  // them kind after kind; the tree build then decides the order the records are stored in.
+  const size_t n_all = (size_t)d.n_spheres + d.n_moving_spheres + d.n_rects + d.n_boxes;
+  if (n_all >= MAX_PRIMS) return fail(ctx, MIRT_ERR_UNSUPPORTED, "too many primitives");
+  const uint32_t first_of_tag[N_PRIM_TAGS] = {0, d.n_spheres, d.n_spheres + d.n_moving_spheres,
+                                              d.n_spheres + d.n_moving_spheres + d.n_rects};
+  std::vector<float4> src(n_all * PRIM_QUADS, make_float4(0, 0, 0, 0));
+  std::vector<uint2> src_ids(n_all);
+  std::vector<uint32_t> boundary_only;
   std::vector<BuildPrim> build;
-  build.reserve((size_t)d.n_spheres + d.n_moving_spheres + d.n_rects + d.n_boxes);
-  auto push_prim = [&](Bounds& b, uint32_t tag, uint32_t index, uint32_t flags) -> bool {
+  build.reserve(n_all);
+  auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+  auto finish = [&](Bounds& b, uint32_t tag, uint32_t g, const mirt_prim_header& h, float time1) -> bool {
+    src[PRIM_QUADS * (size_t)g + 2] = make_float4(bits((h.chain << 2) | tag), bits(h.order),
+                                                  bits(make_material_word(d.materials[h.material].kind, h.material)), time1);
+    src[PRIM_QUADS * (size_t)g + 3] = make_float4(bits(h.flags), 0, 0, 0);
+    src_ids[g] = make_uint2(h.type_index, h.object_index);
     b.pad();
     if (!b.finite()) return false;
-    if (flags & MIRT_PRIM_FLAG_BOUNDARY) return true;
+    if (h.flags & MIRT_PRIM_FLAG_BOUNDARY) { boundary_only.push_back(g); return true; }
     BuildPrim p;
     for (int a = 0; a < 3; ++a) { p.mn[a] = b.mn[a]; p.mx[a] = b.mx[a]; }
-    p.ref = make_leaf(tag, index);
+    p.id = g;
     build.push_back(p);
     return true;
   };
-  std::vector<float4> geo;
-  std::vector<uint2> ids;
-
-  geo.resize((size_t)d.n_spheres * SPHERE_STRIDE); ids.resize(d.n_spheres);
   for (uint32_t i = 0; i < d.n_spheres; ++i) {
     const mirt_sphere& p = d.spheres[i];
-    geo[SPHERE_STRIDE * (size_t)i] = make_float4(p.center[0], p.center[1], p.center[2], p.radius);
-    geo[SPHERE_STRIDE * (size_t)i + 1] = info_of(d, p.h);
-    ids[i] = make_uint2(p.h.type_index, p.h.object_index);
+    const uint32_t g = first_of_tag[TAG_SPHERE] + i;
+    src[PRIM_QUADS * (size_t)g] = make_float4(p.center[0], p.center[1], p.center[2], p.radius);
     Bounds b;
     b.add(chain_to_world(d, p.h.chain, P3{p.center[0], p.center[1], p.center[2]}), std::fabs(p.radius));
-    if (!push_prim(b, TAG_SPHERE, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sphere with non-finite bounds");
+    if (!finish(b, TAG_SPHERE, g, p.h, 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sphere with non-finite bounds");
   }
-  MIRT_HIP(ctx, upload(s.sphere, geo));
-  MIRT_HIP(ctx, upload(s.prim_ids[TAG_SPHERE], ids));
-
-  geo.assign((size_t)d.n_moving_spheres * MSPHERE_STRIDE, make_float4(0, 0, 0, 0));
-  ids.resize(d.n_moving_spheres);
   for (uint32_t i = 0; i < d.n_moving_spheres; ++i) {
     const mirt_moving_sphere& p = d.moving_spheres[i];
-    geo[MSPHERE_STRIDE * (size_t)i] = make_float4(p.center0[0], p.center0[1], p.center0[2], p.radius);
-    geo[MSPHERE_STRIDE * (size_t)i + 1] = make_float4(p.center1[0], p.center1[1], p.center1[2], p.time0);
-    geo[MSPHERE_STRIDE * (size_t)i + 2] = make_float4(p.time1, 0, 0, 0);
-    geo[MSPHERE_STRIDE * (size_t)i + 3] = info_of(d, p.h);
-    ids[i] = make_uint2(p.h.type_index, p.h.object_index);
+    const uint32_t g = first_of_tag[TAG_MOVING_SPHERE] + i;
+    src[PRIM_QUADS * (size_t)g] = make_float4(p.center0[0], p.center0[1], p.center0[2], p.radius);
+    src[PRIM_QUADS * (size_t)g + 1] = make_float4(p.center1[0], p.center1[1], p.center1[2], p.time0);
     Bounds b;
     // the centre is linear in time (objects.rs:132-135): bound the two ends of the valid interval
     for (int e = 0; e < 2; ++e) {
@@ -344,53 +336,53 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
                  p.center0[2] + f * (p.center1[2] - p.center0[2])};
       b.add(chain_to_world(d, p.h.chain, c), std::fabs(p.radius));
     }
-    if (!push_prim(b, TAG_MOVING_SPHERE, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "moving sphere with non-finite bounds");
+    if (!finish(b, TAG_MOVING_SPHERE, g, p.h, p.time1)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "moving sphere with non-finite bounds");
   }
-  MIRT_HIP(ctx, upload(s.msphere, geo));
-  MIRT_HIP(ctx, upload(s.prim_ids[TAG_MOVING_SPHERE], ids));
-
-  geo.assign((size_t)d.n_rects * RECT_STRIDE, make_float4(0, 0, 0, 0));
-  ids.resize(d.n_rects);
   for (uint32_t i = 0; i < d.n_rects; ++i) {
     const mirt_rect& p = d.rects[i];
-    geo[RECT_STRIDE * (size_t)i] = make_float4(p.a0, p.a1, p.b0, p.b1);
-    float axis_bits;
-    std::memcpy(&axis_bits, &p.axis, 4);
-    geo[RECT_STRIDE * (size_t)i + 1] = make_float4(p.k, axis_bits, 0, 0);
-    geo[RECT_STRIDE * (size_t)i + 2] = info_of(d, p.h);
-    ids[i] = make_uint2(p.h.type_index, p.h.object_index);
+    const uint32_t g = first_of_tag[TAG_RECT] + i;
+    src[PRIM_QUADS * (size_t)g] = make_float4(p.a0, p.a1, p.b0, p.b1);
+    src[PRIM_QUADS * (size_t)g + 1] = make_float4(p.k, bits(p.axis), 0, 0);
     float mn[3], mx[3];
     if (p.axis == MIRT_RECT_XY) { mn[0] = p.a0; mx[0] = p.a1; mn[1] = p.b0; mx[1] = p.b1; mn[2] = mx[2] = p.k; }
     else if (p.axis == MIRT_RECT_XZ) { mn[0] = p.a0; mx[0] = p.a1; mn[2] = p.b0; mx[2] = p.b1; mn[1] = mx[1] = p.k; }
     else { mn[1] = p.a0; mx[1] = p.a1; mn[2] = p.b0; mx[2] = p.b1; mn[0] = mx[0] = p.k; }
     Bounds b;
     add_corners(d, p.h.chain, mn, mx, b);
-    if (!push_prim(b, TAG_RECT, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "rect with non-finite bounds");
+    if (!finish(b, TAG_RECT, g, p.h, 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "rect with non-finite bounds");
   }
-  MIRT_HIP(ctx, upload(s.rect, geo));
-  MIRT_HIP(ctx, upload(s.prim_ids[TAG_RECT], ids));
-
-  geo.assign((size_t)d.n_boxes * BOX_STRIDE, make_float4(0, 0, 0, 0));
-  ids.resize(d.n_boxes);
   for (uint32_t i = 0; i < d.n_boxes; ++i) {
     const mirt_box& p = d.boxes[i];
-    geo[BOX_STRIDE * (size_t)i] = make_float4(p.min[0], p.min[1], p.min[2], 0);
-    geo[BOX_STRIDE * (size_t)i + 1] = make_float4(p.max[0], p.max[1], p.max[2], 0);
-    geo[BOX_STRIDE * (size_t)i + 2] = info_of(d, p.h);
-    ids[i] = make_uint2(p.h.type_index, p.h.object_index);
+    const uint32_t g = first_of_tag[TAG_BOX] + i;
+    src[PRIM_QUADS * (size_t)g] = make_float4(p.min[0], p.min[1], p.min[2], 0);
+    src[PRIM_QUADS * (size_t)g + 1] = make_float4(p.max[0], p.max[1], p.max[2], 0);
     Bounds b;
     add_corners(d, p.h.chain, p.min, p.max, b);
-    if (!push_prim(b, TAG_BOX, i, p.h.flags)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "box with non-finite bounds");
+    if (!finish(b, TAG_BOX, g, p.h, 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "box with non-finite bounds");
   }
-  MIRT_HIP(ctx, upload(s.box, geo));
-  MIRT_HIP(ctx, upload(s.prim_ids[TAG_BOX], ids));
 
   // ---- acceleration structure ----------------------------------------------------
   s.n_prims = build.size();
-  BuiltBvh bvh = build_bvh(build, STACK_DEPTH - 2);
+  BuiltBvh bvh = build_bvh(build, STACK_DEPTH - 2, LEAF_MAX_PRIMS);
   if (bvh.height > (uint32_t)STACK_DEPTH - 1) return fail(ctx, MIRT_ERR_UNSUPPORTED, "BVH taller than the traversal stack");
   s.bvh_height = bvh.height;
   MIRT_HIP(ctx, upload(s.nodes, bvh.nodes));
+  // records in tree order, boundary-only records behind them
+  std::vector<float4> rec(n_all * PRIM_QUADS);
+  std::vector<uint2> ids(n_all);
+  std::vector<uint32_t> position(n_all, 0);  // src number -> record index
+  {
+    size_t pos = 0;
+    auto place = [&](uint32_t g) {
+      for (uint32_t k = 0; k < PRIM_QUADS; ++k) rec[PRIM_QUADS * pos + k] = src[PRIM_QUADS * (size_t)g + k];
+      ids[pos] = src_ids[g];
+      position[g] = (uint32_t)pos++;
+    };
+    for (const BuildPrim& bp : build) place(bp.id);
+    for (uint32_t g : boundary_only) place(g);
+  }
+  MIRT_HIP(ctx, upload(s.prims, rec));
+  MIRT_HIP(ctx, upload(s.prim_ids, ids));
 
   // ---- wrappers, media, materials, textures, lights ------------------------------------
   std::vector<uint2> chains(d.n_chains);
@@ -457,14 +449,10 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   v.n_nodes = (uint32_t)bvh.nodes.size();
   v.bvh_height = bvh.height;
   v.n_chains = d.n_chains;
-  v.sphere = s.sphere.as<float4>();
-  v.msphere = s.msphere.as<float4>();
-  v.rect = s.rect.as<float4>();
-  v.box = s.box.as<float4>();
-  v.ids_sphere = s.prim_ids[TAG_SPHERE].as<uint2>();
-  v.ids_msphere = s.prim_ids[TAG_MOVING_SPHERE].as<uint2>();
-  v.ids_rect = s.prim_ids[TAG_RECT].as<uint2>();
-  v.ids_box = s.prim_ids[TAG_BOX].as<uint2>();
+  v.prims = s.prims.as<float4>();
+  v.prim_ids = s.prim_ids.as<uint2>();
+  v.n_prims = (uint32_t)build.size();
+  v.n_chain_ops = d.n_chain_ops;
   v.chains = s.chains.as<uint2>();
   v.chain_ops = s.chain_ops.as<float4>();
   v.n_media = d.n_media;
@@ -472,7 +460,7 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   for (uint32_t i = 0; i < d.n_media; ++i) {
     const mirt_medium& m = d.media[i];
     DMedium& dm = media[i];
-    dm.boundary_ref = make_leaf(m.boundary_tag, m.boundary_index);
+    dm.boundary_ref = make_leaf(m.boundary_tag, position[first_of_tag[m.boundary_tag] + m.boundary_index]);
     dm.neg_inv_density = m.neg_inv_density;
     dm.material_word = make_material_word(d.materials[m.material].kind, m.material);
     dm.chain = m.chain;
@@ -553,6 +541,11 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   const bool count_work = (p.flags & MIRT_RENDER_COUNT_WORK) != 0;
   const bool time_kernels = (p.flags & MIRT_RENDER_TIME_KERNELS) != 0;
   const ExtendConfig extend_cfg = plan_extend(scene->view, ctx->num_cu, pool);
+  if (std::getenv("MIRT_VERBOSE"))
+    std::fprintf(stderr, "mirt: %zu prims, %u nodes, height %u; extend %s, %d x %d threads, %zu B LDS, stack %d; pool %u\n",
+                 scene->n_prims, scene->view.n_nodes, scene->view.bvh_height,
+                 extend_cfg.lds_nodes ? "scene in LDS" : "scene in global memory", extend_cfg.grid, extend_cfg.block,
+                 extend_cfg.lds_bytes, extend_cfg.stack_depth, pool);
   const int shade_grid = std::max(1, std::min(ctx->num_cu * ctx->shade_blocks, (int)((pool + 255u) / 256u)));
 
   std::vector<hipEvent_t> events;  // start/stop pairs: extend, shade, extend, shade, ...

@@ -10,14 +10,20 @@
 
 namespace mirt {
 
-// ---- child / hit references ---------------------------------------------------
-// bit 31 set: leaf.  bits 28..30: tag.  bits 0..27: index inside the tag's array.
-// bit 31 clear: index of an inner node.
+// ---- references ------------------------------------------------------------------
+// Inside the tree (node children, traversal stack):
+//   bit 31 clear: index of an inner node
+//   bit 31 set:   a leaf = (count - 1) in bits 28..30, index of its first primitive record in bits 0..27
+//                 (a leaf's primitives are consecutive records)
+// Hit references (what extend hands to shade, what trace resolves to ids):
+//   bit 31 set, primitive kind (TAG_*) in bits 28..30, record index in bits 0..27;
+//   TAG_MEDIUM + medium number for a constant medium; REF_NONE for a miss.
 constexpr uint32_t REF_LEAF = 0x80000000u;
-constexpr uint32_t REF_NONE = 0xFFFFFFFFu;  // miss / empty tree
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;  // miss / empty tree / traversal finished
 constexpr uint32_t TAG_SPHERE = 0, TAG_MOVING_SPHERE = 1, TAG_RECT = 2, TAG_BOX = 3, TAG_MEDIUM = 6;
 constexpr uint32_t N_PRIM_TAGS = 4;
-constexpr uint32_t MAX_PRIMS_PER_TAG = 1u << 28;
+constexpr uint32_t MAX_PRIMS = (1u << 28) - 1;
+constexpr uint32_t LEAF_MAX_PRIMS = 4;  // primitives per leaf the host builder aims for (the encoding allows 8)
 
 __host__ __device__ inline uint32_t make_leaf(uint32_t tag, uint32_t index) { return REF_LEAF | (tag << 28) | index; }
 __host__ __device__ inline uint32_t ref_tag(uint32_t ref) { return (ref >> 28) & 7u; }
@@ -40,15 +46,16 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 //   n3 = right.max.xyz, unused
 // Child boxes live in the parent so one 64-byte fetch decides both children.
 
-// Primitive records: geometry float4s followed by one info word quad
-//   info = bits(material word), bits(chain index), bits(order = tie-break rank), bits(flags)
-// so that one cache line holds everything a primitive test needs.
-//   sphere         2 x float4: (center, radius) info
-//   moving sphere  4 x float4: (c0, radius) (c1, time0) (time1,-,-,-) info
-//   rect           3 x float4: (a0,a1,b0,b1) (k, bits(axis), -, -) info
-//   box            3 x float4: (min,-) (max,-) info
-// ids: uint2 (type_index, object_index) per primitive, per tag (only read when ids are reported).
-constexpr uint32_t SPHERE_STRIDE = 2, MSPHERE_STRIDE = 4, RECT_STRIDE = 3, BOX_STRIDE = 3;
+// Primitive records: 4 x float4 = one 64-byte line per primitive, in the order the tree lists them
+// (so a leaf's primitives are neighbours); boundary-only primitives follow at the end.
+//   qa = sphere (center, radius) | moving sphere (c0, radius) | rect (a0,a1,b0,b1) | box (min, -)
+//   qb =                         | moving sphere (c1, time0)  | rect (k, bits(axis),-,-) | box (max, -)
+//   qc = bits(chain << 2 | kind), bits(order = tie-break rank), bits(material word), moving sphere: time1
+//   qd = bits(flags), -, -, -
+// Traversal needs qa..qc only; when the scene fits, extend keeps those 48 bytes per primitive in LDS.
+// prim_ids: uint2 (type_index, object_index) per record (only read when ids are reported).
+constexpr uint32_t PRIM_QUADS = 4;      // record stride in global memory
+constexpr uint32_t PRIM_QUADS_LDS = 3;  // record stride of the LDS copy
 
 struct DMaterial {  // 16 B
   uint32_t kind;
@@ -97,16 +104,10 @@ struct DeviceScene {
   uint32_t n_nodes;
   uint32_t bvh_height;  // inner nodes on the longest root-to-leaf path
 
-  const float4* sphere;   // primitive records, layout above
-  const float4* msphere;
-  const float4* rect;
-  const float4* box;
-  // per tag (sphere, moving sphere, rect, box); separate members rather than
-  // an array so a run-time tag selects a pointer without a private-memory copy
-  const uint2* ids_sphere;
-  const uint2* ids_msphere;
-  const uint2* ids_rect;
-  const uint2* ids_box;
+  const float4* prims;  // primitive records, layout above
+  const uint2* prim_ids;
+  uint32_t n_prims;     // records a leaf can point at (boundary-only records come after them)
+  uint32_t n_chain_ops;
 
   const uint2* chains;      // (first_op, n_ops)
   const float4* chain_ops;  // (bits(kind), p0, p1, p2)
@@ -193,8 +194,8 @@ constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
 constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
 // ---- launchers implemented in kernels.hip ------------------------------------
-// How extend is launched for a scene: with the whole BVH staged in LDS when
-// it fits beside the traversal stacks of a 1024-thread block, else from global memory.
+// How extend is launched for a scene: with nodes, primitive records and wrapper chains staged in
+// LDS when they fit beside the traversal stacks of a 1024-thread block, else from global memory.
 struct ExtendConfig {
   bool lds_nodes;
   int block;
