@@ -18,6 +18,10 @@
 
 #include <type_traits>
 
+#ifndef EXTEND_REFILL_MIN
+#define EXTEND_REFILL_MIN 16
+#endif
+
 #include "scene_device.h"
 
 namespace mirt {
@@ -285,65 +289,98 @@ struct RefCode {
 };
 constexpr uint32_t COMPACT_MAX_PRIMS = 4096, COMPACT_MAX_NODES = 32768;
 
-// Closest surface over (t_min, inf): the result of the reference's exhaustive
-// scan -- smallest t, and of equal t the primitive with the higher `order`.
-// `stack` is this lane's column of an LDS stack whose rows are `stride` entries apart.
-// Two nested loops: a lane walks inner nodes until it holds a leaf, the wave
-// then tests the primitives of the leaves its lanes hold together.
+// State of one ray's walk through the tree: the ray, the closest hit so far (smallest t, and of equal t
+// the primitive with the higher `order`, which is what the reference's exhaustive scan returns) and the
+// reference in hand -- an inner node, a leaf, or NONE once nothing is left to visit.
+struct Walk {
+  Ray r;
+  V3 inv;
+  float best_t;
+  uint32_t best_ref, best_order, best_material, cur, sp;
+};
+
+__device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root) {
+  w.r = r;
+  // the reciprocals only steer the conservative box test: the hardware approximation lies well inside its padding
+  w.inv = v3(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+  w.best_t = kInf;
+  w.best_ref = REF_NONE;
+  w.best_order = 0;
+  w.best_material = 0;
+  w.cur = root;
+  w.sp = 0;
+}
+
+// Walks inner nodes until the lane holds a leaf or has nothing left.  `stack` is this lane's column of
+// an LDS stack whose rows are `stride` entries apart.
+template <bool COUNT, bool COMPACT, class Slot>
+__device__ __forceinline__ void walk_nodes(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride,
+                                           Work& work) {
+  using RC = RefCode<COMPACT>;
+  long long t0 = 0;
+  if (COUNT) t0 = clock64();
+  while (!(w.cur & RC::LEAF)) {
+    if (COUNT) ++work.nodes;
+    const float4* n = tb.nodes + 4 * (size_t)w.cur;
+    const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    float tl, tr;
+    const bool hl = slab(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, tl);
+    const bool hr = slab(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, tr);
+    const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
+    if (hl && hr) {
+      const bool left_first = tl <= tr;
+      stack[(w.sp++) * stride] = (Slot)(left_first ? right : left);
+      w.cur = left_first ? left : right;
+    } else if (hl) {
+      w.cur = left;
+    } else if (hr) {
+      w.cur = right;
+    } else {
+      w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
+    }
+  }
+  if (COUNT) work.cycles[MIRT_PHASE_NODES] += clock64() - t0;
+}
+
+// Tests the primitives of the leaf in hand (w.cur must be a leaf other than NONE), then pops.
+template <bool COUNT, int PSTRIDE, bool COMPACT, class Slot>
+__device__ __forceinline__ void walk_leaf(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride,
+                                          Work& work) {
+  using RC = RefCode<COMPACT>;
+  long long t0 = 0;
+  if (COUNT) t0 = clock64();
+  const uint32_t first = w.cur & RC::MASK, last = first + ((w.cur >> RC::SHIFT) & 7u);
+  for (uint32_t index = first; index <= last; ++index) {
+    float t;
+    uint32_t tag, order, material;
+    if (COUNT) ++work.prims;
+    if (record_t<PSTRIDE>(tb, index, w.r, t_min, w.best_t, t, tag, order, material)) {
+      // t == best_t: the later one in the reference's visiting order wins
+      if (t < w.best_t || w.best_ref == REF_NONE || order > w.best_order) {
+        w.best_t = t; w.best_ref = make_leaf(tag, index); w.best_material = material; w.best_order = order;
+      }
+    }
+  }
+  w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
+  if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - t0;
+}
+
+// Closest surface over (t_min, inf) of one ray, start to finish.  Two nested loops: a lane walks inner
+// nodes until it holds a leaf, the wave then tests the primitives of the leaves its lanes hold together.
 template <bool COUNT, int PSTRIDE, bool COMPACT, class Slot>
 __device__ __forceinline__ void closest_surface(const SceneTables& tb, uint32_t root, const Ray& r,
                                                 float t_min, Slot* stack, uint32_t stride, uint32_t& best_ref,
                                                 float& best_t, uint32_t& best_material, Work& work) {
-  using RC = RefCode<COMPACT>;
-  constexpr uint32_t REF_LEAF = RC::LEAF, REF_NONE = RC::NONE;  // shadow the 32-bit codes inside the walk
-  best_ref = mirt::REF_NONE;
-  best_t = kInf;
-  best_material = 0;
-  uint32_t best_order = 0;
-  uint32_t cur = root;  // REF_NONE (leaf bit set) doubles as "no work left"
-  if (cur == REF_NONE) return;
-  const V3 inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-  uint32_t sp = 0;
+  Walk w;
+  walk_begin(w, r, root);
   for (;;) {
-    long long t0 = 0, t1 = 0;
-    if (COUNT) t0 = clock64();
-    while (!(cur & REF_LEAF)) {
-      if (COUNT) ++work.nodes;
-      const float4* n = tb.nodes + 4 * (size_t)cur;
-      const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-      float tl, tr;
-      const bool hl = slab(xyz(n0), xyz(n1), r.o, inv, t_min, best_t, tl);
-      const bool hr = slab(xyz(n2), xyz(n3), r.o, inv, t_min, best_t, tr);
-      const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
-      if (hl && hr) {
-        const bool left_first = tl <= tr;
-        stack[(sp++) * stride] = (Slot)(left_first ? right : left);
-        cur = left_first ? left : right;
-      } else if (hl) {
-        cur = left;
-      } else if (hr) {
-        cur = right;
-      } else {
-        cur = sp ? stack[(--sp) * stride] : REF_NONE;
-      }
-    }
-    if (COUNT) { t1 = clock64(); work.cycles[MIRT_PHASE_NODES] += t1 - t0; }
-    if (cur == REF_NONE) break;
-    const uint32_t first = cur & RC::MASK, last = first + ((cur >> RC::SHIFT) & 7u);
-    for (uint32_t index = first; index <= last; ++index) {
-      float t;
-      uint32_t tag, order, material;
-      if (COUNT) ++work.prims;
-      if (record_t<PSTRIDE>(tb, index, r, t_min, best_t, t, tag, order, material)) {
-        // t == best_t: the later one in the reference's visiting order wins
-        if (t < best_t || best_ref == mirt::REF_NONE || order > best_order) {
-          best_t = t; best_ref = make_leaf(tag, index); best_material = material; best_order = order;
-        }
-      }
-    }
-    cur = sp ? stack[(--sp) * stride] : REF_NONE;
-    if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - t1;
+    walk_nodes<COUNT, COMPACT>(w, tb, t_min, stack, stride, work);
+    if (w.cur == RefCode<COMPACT>::NONE) break;
+    walk_leaf<COUNT, PSTRIDE, COMPACT>(w, tb, t_min, stack, stride, work);
   }
+  best_ref = w.best_ref;
+  best_t = w.best_t;
+  best_material = w.best_material;
 }
 
 // Both roots of the sphere quadratic (objects.rs:42-53), or false when the discriminant is negative.
@@ -802,15 +839,31 @@ __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& to
 }
 
 // ---- extend -----------------------------------------------------------------------
+// A block works through its share of the pool in units of THREADS consecutive slots (a unit lies in one
+// region).  Up to MAX_UNITS units make a batch whose live slots form the list the block's waves pull from.
+constexpr uint32_t MAX_UNITS = 64;
+constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+// A wave fetches new rays once this many of its lanes have none.
+constexpr uint32_t REFILL_MIN = EXTEND_REFILL_MIN;
+
 // Block-shared bookkeeping of extend, filled by the first wave.
 struct ExtendShared {
   uint32_t survivors[N_REGIONS];    // region s carries survivors in its local slots [0, survivors[s])
   uint32_t free_before[N_REGIONS];  // free slots in regions < s: numbers the new paths of region s
+  uint32_t unit_begin[MAX_UNITS];   // live slots in the batch's units before unit k
   uint32_t n_new;                   // camera paths started this iteration
-  uint32_t pad[3];
+  uint32_t next_work;               // next entry of the batch's list to hand out
+  uint32_t total_work;              // entries in the batch's list
+  uint32_t pad;
   MediumEntry media[MIRT_MAX_MEDIA];
 };
 
+// One launch advances every live path by one segment: camera paths are started in the free slots, each
+// live slot's ray finds its closest surface, constant media get their chance, and the slot number goes
+// into the queue of its region that matches the material hit.  The walk itself is the divergent part, so
+// it runs on its own between two coherent passes: lanes whose ray has finished pull the next ray from the
+// block's list instead of waiting for the slowest lane of the wave.
+//
 // LDS_SCENE: the block first stages the whole scene the traversal touches in LDS -- dynamic shared memory
 // holds [bookkeeping][nodes][48-byte primitive records][chain ops][chains][stack] -- so the walk never
 // waits on global memory; otherwise those tables are read from global memory and LDS holds the stack only.
@@ -824,6 +877,8 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
   float4* after = smem + sizeof(ExtendShared) / 16;
   SceneTables tb = global_tables(sc);
   using Slot = typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type;
+  using RC = RefCode<LDS_SCENE>;
+  constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
   Slot* stack = reinterpret_cast<Slot*>(after) + threadIdx.x;
   if (LDS_SCENE) {
     const uint32_t n_node_quads = sc.n_nodes * 4u;
@@ -872,101 +927,163 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
   long long k_begin = 0, ts = 0;
   if (COUNT) k_begin = clock64();
   uint32_t segments = 0;
-  const uint32_t stride = gridDim.x * THREADS;
+  const uint32_t lane = lane_id();
   const uint32_t pixels = rc.width * rc.height;
   const uint32_t n_new = sh.n_new;
-  // every lane of a wave runs the same number of rounds so the ballots below see whole waves
-  const uint32_t rounds = (rc.pool + stride - 1) / stride;
-  for (uint32_t round = 0; round < rounds; ++round) {
-    const uint32_t i = round * stride + blockIdx.x * THREADS + threadIdx.x;  // slot
-    const uint32_t region = slot_region(i);  // the same for the 64 lanes of a wave
-    const uint32_t local = slot_local(i);
-    bool active = false;
-    Ray r;
-    uint32_t pixel = 0, sample_bounce = 0;
+  const uint32_t n_units = rc.pool / THREADS;  // the pool is a whole number of units
+  // live slots of a unit: its region's survivors and new paths fill the region's local slots from 0 up
+  auto live_in_unit = [&](uint32_t unit) -> uint32_t {
+    const uint32_t region = slot_region(unit * THREADS), local0 = slot_local(unit * THREADS);
+    const uint32_t n_surv = sh.survivors[region], before = sh.free_before[region];
+    const uint32_t fresh = n_new > before ? min(n_new - before, rc.region_cap - n_surv) : 0u;
+    const uint32_t live = n_surv + fresh;
+    return live > local0 ? min(live - local0, (uint32_t)THREADS) : 0u;
+  };
+  for (uint32_t first_unit = blockIdx.x; first_unit < n_units; first_unit += MAX_UNITS * gridDim.x) {
+    // ---- the batch's list -----------------------------------------------------------------------
+    if (threadIdx.x < 64) {
+      const uint32_t unit = first_unit + threadIdx.x * gridDim.x;
+      uint32_t total;
+      const uint32_t begin = wave_exclusive_scan(unit < n_units ? live_in_unit(unit) : 0u, total);
+      sh.unit_begin[threadIdx.x] = begin;
+      if (threadIdx.x == 0) { sh.total_work = total; sh.next_work = 0; }
+    }
+    // ---- new camera paths (renderer.rs:215-218, camera.rs:57-68) --------------------------------------
     if (COUNT) ts = clock64();
-    if (i < rc.pool) {
+    for (uint32_t k = 0; k < MAX_UNITS; ++k) {
+      const uint32_t unit = first_unit + k * gridDim.x;
+      if (unit >= n_units) break;
+      const uint32_t i = unit * THREADS + threadIdx.x;  // slot
+      const uint32_t region = slot_region(i);           // the same for the 64 lanes of a wave
+      const uint32_t local = slot_local(i);
       const uint32_t n_surv = sh.survivors[region];
-      if (local < n_surv) {
-        const float4 r0 = cur[4 * (size_t)i], r1 = cur[4 * (size_t)i + 1];
-        r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
-        pixel = __float_as_uint(r1.w);
-        if (sc.n_media != 0) sample_bounce = __float_as_uint(cur[4 * (size_t)i + 2].w);
-        active = true;
-      } else {
-        const uint32_t nth = sh.free_before[region] + (local - n_surv);
-        if (nth < n_new) {
-          // new camera path (renderer.rs:215-218, camera.rs:57-68)
-          const uint64_t g = issued + nth;
-          const uint32_t pass = (uint32_t)(g / pixels);
-          const uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
-          uint32_t x, y;
-          pixel_of(in_pass, rc.width, rc.height, x, y);
-          pixel = y * rc.width + x;
-          const uint32_t sample = rc.first_sample + pass;
-          sample_bounce = sample << 8;
-          Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, rc.key0, rc.key1);
-          const float u = ((float)x + rng_next(rng)) / (float)(rc.width - 1);
-          const float v = ((float)y + rng_next(rng)) / (float)(rc.height - 1);
-          V3 disk;
-          for (;;) {  // vec3.rs:53-60
-            const float dx = rng_range(rng, -1.0f, 1.0f);
-            const float dy = rng_range(rng, -1.0f, 1.0f);
-            disk = v3(dx, dy, 0.0f);
-            if (len2(disk) < 1.0f) break;
+      if (local < n_surv) continue;
+      const uint32_t nth = sh.free_before[region] + (local - n_surv);
+      if (nth >= n_new) continue;
+      const uint64_t g = issued + nth;
+      const uint32_t pass = (uint32_t)(g / pixels);
+      const uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
+      uint32_t x, y;
+      pixel_of(in_pass, rc.width, rc.height, x, y);
+      const uint32_t pixel = y * rc.width + x;
+      const uint32_t sample = rc.first_sample + pass;
+      Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, rc.key0, rc.key1);
+      const float u = ((float)x + rng_next(rng)) / (float)(rc.width - 1);
+      const float v = ((float)y + rng_next(rng)) / (float)(rc.height - 1);
+      V3 disk;
+      for (;;) {  // vec3.rs:53-60
+        const float dx = rng_range(rng, -1.0f, 1.0f);
+        const float dy = rng_range(rng, -1.0f, 1.0f);
+        disk = v3(dx, dy, 0.0f);
+        if (len2(disk) < 1.0f) break;
+      }
+      const mirt_camera& cam = rc.cam;
+      const V3 rd = rc.cam.lens_radius * disk;
+      const V3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]);
+      const V3 offset = cu * rd.x + cv * rd.y;
+      const V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
+      const V3 llc = v3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
+      const V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+      const V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+      const V3 d = llc + u * hor + v * ver - origin - offset;
+      const V3 o = origin + offset;
+      const float time = rng_range(rng, cam.time0, cam.time1);
+      cur[4 * (size_t)i] = make_float4(o.x, o.y, o.z, time);
+      cur[4 * (size_t)i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
+      cur[4 * (size_t)i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
+    }
+    if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
+    __syncthreads();  // the list is published and the new rays are visible to the whole block
+
+    // ---- closest surfaces ---------------------------------------------------------------------------
+    {
+      const uint32_t root = RC::encode(sc.root_ref);
+      const uint32_t total = sh.total_work;
+      Walk w;
+      w.cur = RC::NONE;
+      uint32_t slot = NO_SLOT;
+      bool more = total != 0;  // the same for the whole wave
+      for (;;) {
+        const unsigned long long idle = __ballot(slot == NO_SLOT);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (more && n_idle >= REFILL_MIN) {
+          if (COUNT) ts = clock64();
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&sh.next_work, n_idle);
+          base = __builtin_amdgcn_readfirstlane(base);
+          more = base + n_idle < total;
+          const uint32_t entry = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+          if (slot == NO_SLOT && entry < total) {
+            uint32_t k = 0;
+            while (k + 1 < MAX_UNITS && entry >= sh.unit_begin[k + 1]) ++k;
+            slot = (first_unit + k * gridDim.x) * THREADS + (entry - sh.unit_begin[k]);
+            const float4 r0 = cur[4 * (size_t)slot], r1 = cur[4 * (size_t)slot + 1];
+            Ray r;
+            r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
+            walk_begin(w, r, root);
           }
-          const mirt_camera& cam = rc.cam;
-          const V3 rd = rc.cam.lens_radius * disk;
-          const V3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]);
-          const V3 offset = cu * rd.x + cv * rd.y;
-          const V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
-          const V3 llc = v3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
-          const V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
-          const V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
-          r.d = llc + u * hor + v * ver - origin - offset;
-          r.o = origin + offset;
-          r.time = rng_range(rng, cam.time0, cam.time1);
-          cur[4 * (size_t)i] = make_float4(r.o.x, r.o.y, r.o.z, r.time);
-          cur[4 * (size_t)i + 1] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(pixel));
-          cur[4 * (size_t)i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample_bounce));
-          active = true;
+          if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
+        }
+        if (__ballot(slot != NO_SLOT) == 0ull) break;
+        walk_nodes<COUNT, LDS_SCENE>(w, tb, kTMin, stack, THREADS, work);
+        if (w.cur != RC::NONE) walk_leaf<COUNT, PSTRIDE, LDS_SCENE>(w, tb, kTMin, stack, THREADS, work);
+        if (slot != NO_SLOT && w.cur == RC::NONE) {
+          cur[4 * (size_t)slot + 3] =
+              make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_material), 0.0f);
+          slot = NO_SLOT;
         }
       }
     }
-    uint32_t ref = REF_NONE, material = 0;
-    float t = kInf;
-    if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_LOAD] += now - ts; ts = now; }
-    if (active) {
-      closest_surface<COUNT, LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS, LDS_SCENE>(
-          tb, RefCode<LDS_SCENE>::encode(sc.root_ref), r, kTMin, stack, THREADS, ref, t, material, work);
+    __syncthreads();  // every live slot of the batch now carries its surface hit
+
+    // ---- constant media, then the material queues -------------------------------------------------------
+    for (uint32_t k = 0; k < MAX_UNITS; ++k) {
+      const uint32_t unit = first_unit + k * gridDim.x;
+      if (unit >= n_units) break;
+      const uint32_t n_live = live_in_unit(unit);
+      if (n_live == 0) continue;  // the same for the whole block
       if (COUNT) ts = clock64();
-      if (sc.n_media != 0) {
-        Rng rng = rng_begin(pixel, sample_bounce >> 8, sample_bounce & 255u, STAGE_MEDIA, rc.key0, rc.key1);
-        closest_media(sc, tb, sh.media, r, kTMin, rng, ref, t, material);
+      const uint32_t i = unit * THREADS + threadIdx.x;
+      const uint32_t region = slot_region(i);
+      const bool active = threadIdx.x < n_live;
+      uint32_t ref = REF_NONE, material = 0;
+      if (active) {
+        const float4 r3 = cur[4 * (size_t)i + 3];
+        ref = __float_as_uint(r3.y);
+        material = __float_as_uint(r3.z);
+        if (sc.n_media != 0) {
+          const float4 r0 = cur[4 * (size_t)i], r1 = cur[4 * (size_t)i + 1];
+          const uint32_t sample_bounce = __float_as_uint(cur[4 * (size_t)i + 2].w);
+          Ray r;
+          r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
+          float t = r3.x;
+          const uint32_t surface = ref;
+          Rng rng = rng_begin(__float_as_uint(r1.w), sample_bounce >> 8, sample_bounce & 255u, STAGE_MEDIA, rc.key0, rc.key1);
+          closest_media(sc, tb, sh.media, r, kTMin, rng, ref, t, material);
+          if (ref != surface) cur[4 * (size_t)i + 3] = make_float4(t, __uint_as_float(ref), 0.0f, 0.0f);
+        }
+        ++segments;
       }
       if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_MEDIA] += now - ts; ts = now; }
-      ++segments;
-      cur[4 * (size_t)i + 3] = make_float4(t, __uint_as_float(ref), 0.0f, 0.0f);
+      // Bin by material: the four reservations of the wave go out as one atomic
+      // instruction (lane q adds the count of queue q), all to this region's counters.
+      const int q = !active ? -1 : (ref == REF_NONE ? QUEUE_TERMINATE : queue_of(material));
+      const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
+      uint32_t base = 0;
+      if (lane < 4) {
+        const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+        const uint32_t cnt = (uint32_t)__popcll(mine);
+        if (cnt) base = atomicAdd(&c->region[region].queue_n[lane], cnt);
+      }
+      const uint32_t b0 = __shfl(base, 0), b1 = __shfl(base, 1), b2 = __shfl(base, 2), b3 = __shfl(base, 3);
+      if (q >= 0) {
+        const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
+        const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
+        const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+        queues[((size_t)q * N_REGIONS + region) * rc.region_cap + pos] = i;
+      }
+      if (COUNT) work.cycles[MIRT_PHASE_WRITE] += clock64() - ts;
     }
-    // Bin by material: the four reservations of the wave go out as one atomic
-    // instruction (lane q adds the count of queue q), all to this region's counters.
-    const int q = !active ? -1 : (ref == REF_NONE ? QUEUE_TERMINATE : queue_of(material));
-    const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
-    const uint32_t lane = lane_id();
-    uint32_t base = 0;
-    if (lane < 4) {
-      const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
-      const uint32_t cnt = (uint32_t)__popcll(mine);
-      if (cnt) base = atomicAdd(&c->region[region].queue_n[lane], cnt);
-    }
-    const uint32_t b0 = __shfl(base, 0), b1 = __shfl(base, 1), b2 = __shfl(base, 2), b3 = __shfl(base, 3);
-    if (q >= 0) {
-      const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
-      const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
-      const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
-      queues[((size_t)q * N_REGIONS + region) * rc.region_cap + pos] = i;
-    }
-    if (COUNT) work.cycles[MIRT_PHASE_WRITE] += clock64() - ts;
   }
   if (COUNT) {
     work.cycles[MIRT_PHASE_TOTAL] = clock64() - k_begin;
@@ -980,7 +1097,7 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
         work.cycles[k] = other > work.cycles[k] ? other : work.cycles[k];
       }
     }
-    if (lane_id() == 0) {
+    if (lane == 0) {
       atomicAdd(&work_out->nodes, (unsigned long long)work.nodes);
       atomicAdd(&work_out->prims, (unsigned long long)work.prims);
       atomicAdd(&work_out->segments, (unsigned long long)segments);
