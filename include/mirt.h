@@ -285,6 +285,9 @@ typedef struct mirt_stats {
   double kernel_ms[MIRT_KERNEL_COUNT];         /* summed device time per kernel (MIRT_RENDER_TIME_KERNELS) */
   uint32_t kernel_launches[MIRT_KERNEL_COUNT];
   uint64_t extend_phase_cycles[MIRT_PHASE_COUNT]; /* shader-clock cycles summed over waves (MIRT_RENDER_COUNT_WORK) */
+  uint64_t node_wave_steps; /* wave-wide turns spent stepping down the tree: nodes_visited / (64 * this) is the
+                               share of lanes doing useful work in them   (MIRT_RENDER_COUNT_WORK) */
+  uint64_t prim_wave_steps; /* the same for primitive tests */
 } mirt_stats;
 
 typedef struct mirt_ray {

@@ -16,11 +16,9 @@
 // add is harmless (the conservative box test) it is written explicitly.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
-#ifndef EXTEND_REFILL_MIN
-#define EXTEND_REFILL_MIN 16
-#endif
 
 #include "scene_device.h"
 
@@ -270,7 +268,8 @@ __device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min
 }
 
 struct Work {
-  uint32_t nodes, prims;
+  uint32_t nodes, prims;            // steps down the tree and primitive tests, per lane
+  uint32_t wave_nodes, wave_prims;  // the same counted once per wave instruction stream (lane 0 only)
   long long cycles[MIRT_PHASE_COUNT];
 };
 
@@ -311,72 +310,66 @@ __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root)
   w.sp = 0;
 }
 
-// Walks inner nodes until the lane holds a leaf or has nothing left.  `stack` is this lane's column of
-// an LDS stack whose rows are `stride` entries apart.
-template <bool COUNT, bool COMPACT, class Slot>
-__device__ __forceinline__ void walk_nodes(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride,
-                                           Work& work) {
+// One step down the tree (w.cur must be an inner node): both child boxes are tested, the nearer one that
+// is hit becomes the reference in hand, the other one waits on the stack.  `stack` is this lane's column
+// of an LDS stack whose rows are `stride` entries apart.
+template <bool COMPACT, class Slot>
+__device__ __forceinline__ void node_step(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride) {
   using RC = RefCode<COMPACT>;
-  long long t0 = 0;
-  if (COUNT) t0 = clock64();
-  while (!(w.cur & RC::LEAF)) {
-    if (COUNT) ++work.nodes;
-    const float4* n = tb.nodes + 4 * (size_t)w.cur;
-    const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-    float tl, tr;
-    const bool hl = slab(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, tl);
-    const bool hr = slab(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, tr);
-    const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
-    if (hl && hr) {
-      const bool left_first = tl <= tr;
-      stack[(w.sp++) * stride] = (Slot)(left_first ? right : left);
-      w.cur = left_first ? left : right;
-    } else if (hl) {
-      w.cur = left;
-    } else if (hr) {
-      w.cur = right;
-    } else {
-      w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
-    }
+  const float4* n = tb.nodes + 4 * (size_t)w.cur;
+  const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+  float tl, tr;
+  const bool hl = slab(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, tl);
+  const bool hr = slab(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, tr);
+  const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
+  if (hl && hr) {
+    const bool left_first = tl <= tr;
+    stack[(w.sp++) * stride] = (Slot)(left_first ? right : left);
+    w.cur = left_first ? left : right;
+  } else if (hl) {
+    w.cur = left;
+  } else if (hr) {
+    w.cur = right;
+  } else {
+    w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
   }
-  if (COUNT) work.cycles[MIRT_PHASE_NODES] += clock64() - t0;
 }
 
-// Tests the primitives of the leaf in hand (w.cur must be a leaf other than NONE), then pops.
-template <bool COUNT, int PSTRIDE, bool COMPACT, class Slot>
-__device__ __forceinline__ void walk_leaf(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride,
-                                          Work& work) {
+// Tests the first primitive of the leaf in hand (w.cur must be a leaf other than NONE); the rest of the
+// leaf stays in hand, and after its last primitive the next reference comes off the stack.
+template <int PSTRIDE, bool COMPACT, class Slot>
+__device__ __forceinline__ void prim_step(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride) {
   using RC = RefCode<COMPACT>;
-  long long t0 = 0;
-  if (COUNT) t0 = clock64();
-  const uint32_t first = w.cur & RC::MASK, last = first + ((w.cur >> RC::SHIFT) & 7u);
-  for (uint32_t index = first; index <= last; ++index) {
-    float t;
-    uint32_t tag, order, material;
-    if (COUNT) ++work.prims;
-    if (record_t<PSTRIDE>(tb, index, w.r, t_min, w.best_t, t, tag, order, material)) {
-      // t == best_t: the later one in the reference's visiting order wins
-      if (t < w.best_t || w.best_ref == REF_NONE || order > w.best_order) {
-        w.best_t = t; w.best_ref = make_leaf(tag, index); w.best_material = material; w.best_order = order;
-      }
+  const uint32_t index = w.cur & RC::MASK;
+  float t;
+  uint32_t tag, order, material;
+  if (record_t<PSTRIDE>(tb, index, w.r, t_min, w.best_t, t, tag, order, material)) {
+    // t == best_t: the later one in the reference's visiting order wins
+    if (t < w.best_t || w.best_ref == REF_NONE || order > w.best_order) {
+      w.best_t = t; w.best_ref = make_leaf(tag, index); w.best_material = material; w.best_order = order;
     }
   }
-  w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
-  if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - t0;
+  if ((w.cur >> RC::SHIFT) & 7u) w.cur += 1u - (1u << RC::SHIFT);  // one fewer left, starting one further
+  else w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
 }
 
 // Closest surface over (t_min, inf) of one ray, start to finish.  Two nested loops: a lane walks inner
-// nodes until it holds a leaf, the wave then tests the primitives of the leaves its lanes hold together.
+// nodes until it holds a leaf, the wave then tests the primitives its lanes hold together.
 template <bool COUNT, int PSTRIDE, bool COMPACT, class Slot>
 __device__ __forceinline__ void closest_surface(const SceneTables& tb, uint32_t root, const Ray& r,
                                                 float t_min, Slot* stack, uint32_t stride, uint32_t& best_ref,
                                                 float& best_t, uint32_t& best_material, Work& work) {
   Walk w;
   walk_begin(w, r, root);
+  using RC = RefCode<COMPACT>;
   for (;;) {
-    walk_nodes<COUNT, COMPACT>(w, tb, t_min, stack, stride, work);
-    if (w.cur == RefCode<COMPACT>::NONE) break;
-    walk_leaf<COUNT, PSTRIDE, COMPACT>(w, tb, t_min, stack, stride, work);
+    while (!(w.cur & RC::LEAF)) {
+      if (COUNT) ++work.nodes;
+      node_step<COMPACT>(w, tb, t_min, stack, stride);
+    }
+    if (w.cur == RC::NONE) break;
+    if (COUNT) ++work.prims;
+    prim_step<PSTRIDE, COMPACT>(w, tb, t_min, stack, stride);
   }
   best_ref = w.best_ref;
   best_t = w.best_t;
@@ -839,43 +832,40 @@ __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& to
 }
 
 // ---- extend -----------------------------------------------------------------------
-// A block works through its share of the pool in units of THREADS consecutive slots (a unit lies in one
-// region).  Up to MAX_UNITS units make a batch whose live slots form the list the block's waves pull from.
-constexpr uint32_t MAX_UNITS = 64;
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
-// A wave fetches new rays once this many of its lanes have none.
-constexpr uint32_t REFILL_MIN = EXTEND_REFILL_MIN;
 
 // Block-shared bookkeeping of extend, filled by the first wave.
 struct ExtendShared {
-  uint32_t survivors[N_REGIONS];    // region s carries survivors in its local slots [0, survivors[s])
-  uint32_t free_before[N_REGIONS];  // free slots in regions < s: numbers the new paths of region s
-  uint32_t unit_begin[MAX_UNITS];   // live slots in the batch's units before unit k
-  uint32_t n_new;                   // camera paths started this iteration
-  uint32_t next_work;               // next entry of the batch's list to hand out
-  uint32_t total_work;              // entries in the batch's list
-  uint32_t pad;
-  MediumEntry media[MIRT_MAX_MEDIA];
+  uint32_t n_surv;     // the region carries survivors in its local slots [0, n_surv)
+  uint32_t n_fresh;    // camera paths started in the region this iteration, in the slots after the survivors
+  uint32_t first_new;  // number of the region's first new path among this iteration's new paths
+  uint32_t next_work;  // next local slot to hand out
+  uint32_t queue_n[N_QUEUES];
 };
 
-// One launch advances every live path by one segment: camera paths are started in the free slots, each
-// live slot's ray finds its closest surface, constant media get their chance, and the slot number goes
-// into the queue of its region that matches the material hit.  The walk itself is the divergent part, so
-// it runs on its own between two coherent passes: lanes whose ray has finished pull the next ray from the
-// block's list instead of waiting for the slowest lane of the wave.
+// One launch advances every live path by one segment; block s does region s.  Camera paths are started
+// in the region's free slots, then each live slot's ray finds its closest surface and the slot number
+// goes into the region's queue for the material hit (constant media get their chance in shade).  The
+// walk is the divergent part: lanes whose ray has finished pull the next ray of the region instead of
+// waiting for the slowest lane of the wave.
 //
 // LDS_SCENE: the block first stages the whole scene the traversal touches in LDS -- dynamic shared memory
 // holds [bookkeeping][nodes][48-byte primitive records][chain ops][chains][stack] -- so the walk never
 // waits on global memory; otherwise those tables are read from global memory and LDS holds the stack only.
-template <bool COUNT, bool LDS_SCENE, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst rc, float4* __restrict__ cur,
-                                                    IterCounters* counters, int parity, WorkCounters* work_out,
-                                                    uint32_t* __restrict__ queues) {
+template <bool COUNT, bool LDS_SCENE>
+__global__ __launch_bounds__(EXTEND_THREADS) void k_extend(DeviceScene sc, RenderConst rc, float4* __restrict__ cur,
+                                                           IterCounters* counters, int parity, WorkCounters* work_out,
+                                                           uint32_t* __restrict__ queues, uint32_t refill_min,
+                                                           uint32_t node_min) {
+  constexpr int THREADS = EXTEND_THREADS;
   extern __shared__ float4 smem[];
   static_assert(sizeof(ExtendShared) % 16 == 0, "keeps the node array 16-byte aligned");
+  static_assert(N_REGIONS == 256, "the first wave looks after four regions per lane");
   ExtendShared& sh = *reinterpret_cast<ExtendShared*>(smem);
   float4* after = smem + sizeof(ExtendShared) / 16;
   SceneTables tb = global_tables(sc);
+  long long block_begin = 0;
+  if (COUNT) block_begin = wall_clock64();
   using Slot = typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type;
   using RC = RefCode<LDS_SCENE>;
   constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
@@ -901,26 +891,35 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
     stack = reinterpret_cast<Slot*>(l_chains + ((sc.n_chains + 1u) & ~1u)) + threadIdx.x;
   }
 
+  const uint32_t region = blockIdx.x;
   IterCounters* c = counters + parity;
   IterCounters* nx = counters + (parity ^ 1);
   const uint64_t issued = c->issued;
-  if (threadIdx.x < 64) {  // N_REGIONS == 64: one lane per region
-    const uint32_t n = c->region[threadIdx.x].n_cur;
+  if (threadIdx.x < 64) {
+    // New paths are numbered through the free slots of region 0, then region 1, ...: every block works
+    // out where its own region's share starts.  Lane l looks after regions 4l .. 4l+3.
+    const uint32_t r4 = threadIdx.x * 4;
+    const uint32_t f0 = rc.region_cap - c->region[r4].n_cur, f1 = rc.region_cap - c->region[r4 + 1].n_cur;
+    const uint32_t f2 = rc.region_cap - c->region[r4 + 2].n_cur, f3 = rc.region_cap - c->region[r4 + 3].n_cur;
     uint32_t total_free;
-    const uint32_t before = wave_exclusive_scan(rc.region_cap - n, total_free);
-    sh.survivors[threadIdx.x] = n;
-    sh.free_before[threadIdx.x] = before;
+    const uint32_t before = wave_exclusive_scan(f0 + f1 + f2 + f3, total_free);
     const uint64_t remaining = rc.total_paths - issued;
     const uint32_t n_new = remaining < (uint64_t)total_free ? (uint32_t)remaining : total_free;
-    if (threadIdx.x == 0) sh.n_new = n_new;
-    if (blockIdx.x == 0) {  // the other parity's counters start the next iteration from zero
-      RegionCounters& z = nx->region[threadIdx.x];
-      z.n_cur = 0;
-      z.queue_n[0] = 0; z.queue_n[1] = 0; z.queue_n[2] = 0; z.queue_n[3] = 0;
+    if (threadIdx.x == region / 4) {
+      const uint32_t sub = region & 3u;
+      const uint32_t mine = sub == 0 ? f0 : (sub == 1 ? f1 : (sub == 2 ? f2 : f3));
+      const uint32_t first = before + (sub > 0 ? f0 : 0u) + (sub > 1 ? f1 : 0u) + (sub > 2 ? f2 : 0u);
+      sh.n_surv = rc.region_cap - mine;
+      sh.first_new = first;
+      sh.n_fresh = n_new > first ? min(n_new - first, mine) : 0u;
+      sh.next_work = 0;
+      sh.queue_n[0] = 0; sh.queue_n[1] = 0; sh.queue_n[2] = 0; sh.queue_n[3] = 0;
+    }
+    if (region == 0) {  // shade counts the survivors of this iteration into the other parity's counters
+      nx->region[r4].n_cur = 0; nx->region[r4 + 1].n_cur = 0; nx->region[r4 + 2].n_cur = 0; nx->region[r4 + 3].n_cur = 0;
       if (threadIdx.x == 0) nx->issued = issued + n_new;
     }
   }
-  stage_media(sc, sh.media);
   __syncthreads();
 
   Work work{};
@@ -928,41 +927,22 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
   if (COUNT) k_begin = clock64();
   uint32_t segments = 0;
   const uint32_t lane = lane_id();
-  const uint32_t pixels = rc.width * rc.height;
-  const uint32_t n_new = sh.n_new;
-  const uint32_t n_units = rc.pool / THREADS;  // the pool is a whole number of units
-  // live slots of a unit: its region's survivors and new paths fill the region's local slots from 0 up
-  auto live_in_unit = [&](uint32_t unit) -> uint32_t {
-    const uint32_t region = slot_region(unit * THREADS), local0 = slot_local(unit * THREADS);
-    const uint32_t n_surv = sh.survivors[region], before = sh.free_before[region];
-    const uint32_t fresh = n_new > before ? min(n_new - before, rc.region_cap - n_surv) : 0u;
-    const uint32_t live = n_surv + fresh;
-    return live > local0 ? min(live - local0, (uint32_t)THREADS) : 0u;
-  };
-  for (uint32_t first_unit = blockIdx.x; first_unit < n_units; first_unit += MAX_UNITS * gridDim.x) {
-    // ---- the batch's list -----------------------------------------------------------------------
-    if (threadIdx.x < 64) {
-      const uint32_t unit = first_unit + threadIdx.x * gridDim.x;
-      uint32_t total;
-      const uint32_t begin = wave_exclusive_scan(unit < n_units ? live_in_unit(unit) : 0u, total);
-      sh.unit_begin[threadIdx.x] = begin;
-      if (threadIdx.x == 0) { sh.total_work = total; sh.next_work = 0; }
-    }
-    // ---- new camera paths (renderer.rs:215-218, camera.rs:57-68) --------------------------------------
-    if (COUNT) ts = clock64();
-    for (uint32_t k = 0; k < MAX_UNITS; ++k) {
-      const uint32_t unit = first_unit + k * gridDim.x;
-      if (unit >= n_units) break;
-      const uint32_t i = unit * THREADS + threadIdx.x;  // slot
-      const uint32_t region = slot_region(i);           // the same for the 64 lanes of a wave
-      const uint32_t local = slot_local(i);
-      const uint32_t n_surv = sh.survivors[region];
-      if (local < n_surv) continue;
-      const uint32_t nth = sh.free_before[region] + (local - n_surv);
-      if (nth >= n_new) continue;
-      const uint64_t g = issued + nth;
+  const uint32_t n_surv = sh.n_surv, n_fresh = sh.n_fresh, first_new = sh.first_new;
+  const size_t slot0 = (size_t)region * rc.region_cap;
+
+  // ---- new camera paths (renderer.rs:215-218, camera.rs:57-68) ----------------------------------------
+  if (COUNT) ts = clock64();
+  {
+    const uint32_t pixels = rc.width * rc.height;
+    for (uint32_t k = threadIdx.x; k < n_fresh; k += THREADS) {
+      const size_t i = slot0 + n_surv + k;
+      const uint64_t g = issued + first_new + k;
       const uint32_t pass = (uint32_t)(g / pixels);
-      const uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
+      uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
+      // Consecutive groups of 64 paths start far apart in the image, so that every region's new paths are a
+      // sample of the whole frame and the regions cost about the same to trace.
+      const uint32_t group = in_pass >> 6;
+      if (group < rc.n_groups) in_pass = (((group * rc.group_stride) % rc.n_groups) << 6) | (in_pass & 63u);
       uint32_t x, y;
       pixel_of(in_pass, rc.width, rc.height, x, y);
       const uint32_t pixel = y * rc.width + x;
@@ -988,103 +968,93 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
       const V3 d = llc + u * hor + v * ver - origin - offset;
       const V3 o = origin + offset;
       const float time = rng_range(rng, cam.time0, cam.time1);
-      cur[4 * (size_t)i] = make_float4(o.x, o.y, o.z, time);
-      cur[4 * (size_t)i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
-      cur[4 * (size_t)i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
+      cur[4 * i] = make_float4(o.x, o.y, o.z, time);
+      cur[4 * i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
+      cur[4 * i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
     }
-    if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
-    __syncthreads();  // the list is published and the new rays are visible to the whole block
+  }
+  if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
+  __syncthreads();  // the new rays are visible to the whole block
 
-    // ---- closest surfaces ---------------------------------------------------------------------------
-    {
-      const uint32_t root = RC::encode(sc.root_ref);
-      const uint32_t total = sh.total_work;
-      Walk w;
-      w.cur = RC::NONE;
-      uint32_t slot = NO_SLOT;
-      bool more = total != 0;  // the same for the whole wave
-      for (;;) {
-        const unsigned long long idle = __ballot(slot == NO_SLOT);
-        const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (more && n_idle >= REFILL_MIN) {
-          if (COUNT) ts = clock64();
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(&sh.next_work, n_idle);
-          base = __builtin_amdgcn_readfirstlane(base);
-          more = base + n_idle < total;
-          const uint32_t entry = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+  // ---- closest surfaces ---------------------------------------------------------------------------
+  {
+    const uint32_t root = RC::encode(sc.root_ref);
+    const uint32_t total = n_surv + n_fresh;
+    uint32_t* const region_queues = queues + (size_t)region * rc.region_cap;
+    const size_t queue_stride = (size_t)N_REGIONS * rc.region_cap;
+    Walk w;
+    w.cur = RC::NONE;
+    uint32_t slot = NO_SLOT;  // local slot of the ray this lane is walking
+    bool more = total != 0;   // rays left to hand out, as far as this wave knows
+    // Every turn of this loop the wave first hands in finished rays and fetches new ones if enough lanes
+    // are without work, then steps down the tree until (almost) every lane holds a leaf, then tests one
+    // primitive in every lane that holds a leaf.
+    for (;;) {
+      const bool done = slot != NO_SLOT && w.cur == RC::NONE;
+      const unsigned long long m_done = __ballot(done);
+      const unsigned long long m_out = m_done | __ballot(slot == NO_SLOT);
+      const uint32_t n_out = (uint32_t)__popcll(m_out);
+      if (n_out == 64u && m_done == 0ull && !more) break;
+      if ((m_done != 0ull || more) && (n_out >= refill_min || n_out == 64u)) {
+        if (COUNT) ts = clock64();
+        // Rays that are done leave their hit in the record and their slot in the queue of the material hit.
+        // Lane q reserves queue q's entries for the whole wave in the block's LDS counters; lane 4 takes
+        // the wave's new rays off the region's list.
+        const int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(w.best_material));
+        const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
+        uint32_t got = 0;
+        if (lane < 4) {
+          const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+          const uint32_t cnt = (uint32_t)__popcll(mine);
+          if (cnt) got = atomicAdd(&sh.queue_n[lane], cnt);
+        } else if (lane == 4 && more) {
+          got = atomicAdd(&sh.next_work, n_out);
+        }
+        const uint32_t b0 = __builtin_amdgcn_readlane(got, 0), b1 = __builtin_amdgcn_readlane(got, 1);
+        const uint32_t b2 = __builtin_amdgcn_readlane(got, 2), b3 = __builtin_amdgcn_readlane(got, 3);
+        const uint32_t base = __builtin_amdgcn_readlane(got, 4);
+        if (done) {
+          const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
+          const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
+          const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+          region_queues[(size_t)q * queue_stride + pos] = (uint32_t)(slot0 + slot);
+          cur[4 * (slot0 + slot) + 3] = make_float4(w.best_t, __uint_as_float(w.best_ref), 0.0f, 0.0f);
+          slot = NO_SLOT;
+          ++segments;
+        }
+        if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_WRITE] += now - ts; ts = now; }
+        if (more) {
+          more = base + n_out < total;
+          const uint32_t entry = base + (uint32_t)__popcll(m_out & ((1ull << lane) - 1ull));
           if (slot == NO_SLOT && entry < total) {
-            uint32_t k = 0;
-            while (k + 1 < MAX_UNITS && entry >= sh.unit_begin[k + 1]) ++k;
-            slot = (first_unit + k * gridDim.x) * THREADS + (entry - sh.unit_begin[k]);
-            const float4 r0 = cur[4 * (size_t)slot], r1 = cur[4 * (size_t)slot + 1];
+            slot = entry;
+            const float4 r0 = cur[4 * (slot0 + slot)], r1 = cur[4 * (slot0 + slot) + 1];
             Ray r;
             r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
             walk_begin(w, r, root);
           }
-          if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
         }
-        if (__ballot(slot != NO_SLOT) == 0ull) break;
-        walk_nodes<COUNT, LDS_SCENE>(w, tb, kTMin, stack, THREADS, work);
-        if (w.cur != RC::NONE) walk_leaf<COUNT, PSTRIDE, LDS_SCENE>(w, tb, kTMin, stack, THREADS, work);
-        if (slot != NO_SLOT && w.cur == RC::NONE) {
-          cur[4 * (size_t)slot + 3] =
-              make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_material), 0.0f);
-          slot = NO_SLOT;
-        }
+        if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
       }
-    }
-    __syncthreads();  // every live slot of the batch now carries its surface hit
-
-    // ---- constant media, then the material queues -------------------------------------------------------
-    for (uint32_t k = 0; k < MAX_UNITS; ++k) {
-      const uint32_t unit = first_unit + k * gridDim.x;
-      if (unit >= n_units) break;
-      const uint32_t n_live = live_in_unit(unit);
-      if (n_live == 0) continue;  // the same for the whole block
       if (COUNT) ts = clock64();
-      const uint32_t i = unit * THREADS + threadIdx.x;
-      const uint32_t region = slot_region(i);
-      const bool active = threadIdx.x < n_live;
-      uint32_t ref = REF_NONE, material = 0;
-      if (active) {
-        const float4 r3 = cur[4 * (size_t)i + 3];
-        ref = __float_as_uint(r3.y);
-        material = __float_as_uint(r3.z);
-        if (sc.n_media != 0) {
-          const float4 r0 = cur[4 * (size_t)i], r1 = cur[4 * (size_t)i + 1];
-          const uint32_t sample_bounce = __float_as_uint(cur[4 * (size_t)i + 2].w);
-          Ray r;
-          r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
-          float t = r3.x;
-          const uint32_t surface = ref;
-          Rng rng = rng_begin(__float_as_uint(r1.w), sample_bounce >> 8, sample_bounce & 255u, STAGE_MEDIA, rc.key0, rc.key1);
-          closest_media(sc, tb, sh.media, r, kTMin, rng, ref, t, material);
-          if (ref != surface) cur[4 * (size_t)i + 3] = make_float4(t, __uint_as_float(ref), 0.0f, 0.0f);
-        }
-        ++segments;
+      while (!(w.cur & RC::LEAF)) {
+        if (COUNT) { ++work.nodes; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_nodes; }
+        node_step<LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+        // the last few lanes still on their way down do not keep the others waiting
+        if ((uint32_t)__popcll(__ballot(!(w.cur & RC::LEAF))) < node_min) break;
       }
-      if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_MEDIA] += now - ts; ts = now; }
-      // Bin by material: the four reservations of the wave go out as one atomic
-      // instruction (lane q adds the count of queue q), all to this region's counters.
-      const int q = !active ? -1 : (ref == REF_NONE ? QUEUE_TERMINATE : queue_of(material));
-      const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
-      uint32_t base = 0;
-      if (lane < 4) {
-        const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
-        const uint32_t cnt = (uint32_t)__popcll(mine);
-        if (cnt) base = atomicAdd(&c->region[region].queue_n[lane], cnt);
+      if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_NODES] += now - ts; ts = now; }
+      if ((w.cur & RC::LEAF) && w.cur != RC::NONE) {
+        if (COUNT) { ++work.prims; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_prims; }
+        prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, stack, THREADS);
       }
-      const uint32_t b0 = __shfl(base, 0), b1 = __shfl(base, 1), b2 = __shfl(base, 2), b3 = __shfl(base, 3);
-      if (q >= 0) {
-        const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
-        const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
-        const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
-        queues[((size_t)q * N_REGIONS + region) * rc.region_cap + pos] = i;
-      }
-      if (COUNT) work.cycles[MIRT_PHASE_WRITE] += clock64() - ts;
+      if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - ts;
     }
   }
+  __syncthreads();
+  if (threadIdx.x < N_QUEUES) c->region[region].queue_n[threadIdx.x] = sh.queue_n[threadIdx.x];
+  if (COUNT && threadIdx.x == 0) work_out->block_busy[region] += (unsigned long long)(wall_clock64() - block_begin);
+
   if (COUNT) {
     work.cycles[MIRT_PHASE_TOTAL] = clock64() - k_begin;
     // one atomic per wave; a lane's phase clocks stop when it leaves a loop early, so the wave's time is the max
@@ -1092,6 +1062,8 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
       work.nodes += __shfl_down(work.nodes, off);
       work.prims += __shfl_down(work.prims, off);
       segments += __shfl_down(segments, off);
+      work.wave_nodes += __shfl_down(work.wave_nodes, off);
+      work.wave_prims += __shfl_down(work.wave_prims, off);
       for (int k = 0; k < MIRT_PHASE_COUNT; ++k) {
         const long long other = __shfl_down(work.cycles[k], off);
         work.cycles[k] = other > work.cycles[k] ? other : work.cycles[k];
@@ -1100,6 +1072,8 @@ __global__ __launch_bounds__(THREADS) void k_extend(DeviceScene sc, RenderConst 
     if (lane == 0) {
       atomicAdd(&work_out->nodes, (unsigned long long)work.nodes);
       atomicAdd(&work_out->prims, (unsigned long long)work.prims);
+      atomicAdd(&work_out->wave_nodes, (unsigned long long)work.wave_nodes);
+      atomicAdd(&work_out->wave_prims, (unsigned long long)work.wave_prims);
       atomicAdd(&work_out->segments, (unsigned long long)segments);
       for (int k = 0; k < MIRT_PHASE_COUNT; ++k) atomicAdd(&work_out->cycles[k], (unsigned long long)work.cycles[k]);
     }
@@ -1118,25 +1092,26 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderC
   // material of one region.  seg_start[k] = first virtual index of segment k.
   __shared__ uint32_t seg_start[N_SEGMENTS + 1];
   __shared__ uint32_t seg_count[N_SEGMENTS];
+  __shared__ MediumEntry media[MIRT_MAX_MEDIA];
+  stage_media(sc, media);
+  const SceneTables tb = global_tables(sc);
   IterCounters* c = counters + parity;
   IterCounters* nx = counters + (parity ^ 1);
   if (threadIdx.x < 64) {  // each lane of the first wave owns N_SEGMENTS / 64 consecutive segments
     constexpr uint32_t PER = N_SEGMENTS / 64;
-    uint32_t cnt[PER], sum = 0;
-#pragma unroll
+    uint32_t sum = 0;
     for (uint32_t k = 0; k < PER; ++k) {
       const uint32_t seg = threadIdx.x * PER + k;
-      cnt[k] = c->region[seg % N_REGIONS].queue_n[seg / N_REGIONS];
-      sum += (cnt[k] + 63u) & ~63u;
+      const uint32_t cnt = c->region[seg % N_REGIONS].queue_n[seg / N_REGIONS];
+      seg_count[seg] = cnt;
+      sum += (cnt + 63u) & ~63u;
     }
     uint32_t total;
     uint32_t start = wave_exclusive_scan(sum, total);
-#pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
       const uint32_t seg = threadIdx.x * PER + k;
       seg_start[seg] = start;
-      seg_count[seg] = cnt[k];
-      start += (cnt[k] + 63u) & ~63u;
+      start += (seg_count[seg] + 63u) & ~63u;
     }
     if (threadIdx.x == 63) seg_start[N_SEGMENTS] = total;
   }
@@ -1172,8 +1147,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderC
       beta = xyz(r2);
       sample = __float_as_uint(r2.w) >> 8;
       bounce = __float_as_uint(r2.w) & 255u;
-      const float t = r3.x;
-      const uint32_t ref = __float_as_uint(r3.y);
+      float t = r3.x;
+      uint32_t ref = __float_as_uint(r3.y);
+      if (sc.n_media != 0) {  // extend found the closest surface; the media in front of it get their chance now
+        uint32_t material = 0;
+        Rng mrng = rng_begin(pixel, sample, bounce, STAGE_MEDIA, rc.key0, rc.key1);
+        closest_media(sc, tb, media, r, kTMin, mrng, ref, t, material);
+      }
 
       V3 term = v3(0.0f, 0.0f, 0.0f);  // radiance that ends the path
       if (ref == REF_NONE) {
@@ -1244,7 +1224,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderC
     // survivors are compacted into the same region of the other buffer (one atomic per wave)
     const uint32_t local = wave_reserve(alive, &nx->region[region].n_cur);
     if (alive) {
-      const size_t slot = region_slot(region, local);
+      const size_t slot = (size_t)region * rc.region_cap + local;
       next[4 * slot] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
       next[4 * slot + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
       next[4 * slot + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
@@ -1311,46 +1291,51 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
 }  // namespace
 
 // ---- launchers ------------------------------------------------------------------------
-ExtendConfig plan_extend(const DeviceScene& sc, int num_cu, uint32_t pool) {
+ExtendConfig plan_extend(const DeviceScene& sc) {
   ExtendConfig cfg{};
+  cfg.block = EXTEND_THREADS;
+  cfg.grid = N_REGIONS;
   // a stack entry per inner node on the path plus the pending sibling of the last one
   const int depth = (int)sc.bvh_height + 2;
   const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * PRIM_QUADS_LDS * 16 +
                              (size_t)sc.n_chain_ops * 16 + (size_t)((sc.n_chains + 1u) & ~1u) * 8;
   // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes
-  const size_t lds_total = sizeof(ExtendShared) + scene_bytes + (size_t)depth * LDS_BLOCK_THREADS * 2;
+  const size_t lds_total = sizeof(ExtendShared) + scene_bytes + (size_t)depth * EXTEND_THREADS * 2;
   if (lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
     cfg.lds_nodes = true;
-    cfg.block = LDS_BLOCK_THREADS;
     cfg.stack_depth = depth;
     cfg.lds_bytes = lds_total;
-    cfg.grid = num_cu;
   } else {
     cfg.lds_nodes = false;
-    cfg.block = BLOCK_THREADS;
     cfg.stack_depth = STACK_DEPTH;
-    cfg.lds_bytes = sizeof(ExtendShared) + (size_t)STACK_DEPTH * BLOCK_THREADS * 4;
-    cfg.grid = num_cu * 5;  // 32 KiB of stack per block: five blocks share a CU's LDS
+    cfg.lds_bytes = sizeof(ExtendShared) + (size_t)STACK_DEPTH * EXTEND_THREADS * 4;
   }
-  const int needed = (int)((pool + (uint32_t)cfg.block - 1) / (uint32_t)cfg.block);
-  if (cfg.grid > needed) cfg.grid = needed;
-  if (cfg.grid < 1) cfg.grid = 1;
+  cfg.refill_min = 16;
+  cfg.node_min = 16;
+  if (const char* e = std::getenv("MIRT_EXTEND_REFILL")) {  // tuning aids
+    const long v = std::strtol(e, nullptr, 10);
+    if (v >= 1 && v <= 64) cfg.refill_min = (uint32_t)v;
+  }
+  if (const char* e = std::getenv("MIRT_EXTEND_NODE_MIN")) {
+    const long v = std::strtol(e, nullptr, 10);
+    if (v >= 1 && v <= 64) cfg.node_min = (uint32_t)v;
+  }
   return cfg;
 }
 
-template <bool COUNT, bool LDS_SCENE, int THREADS>
+template <bool COUNT, bool LDS_SCENE>
 static hipError_t launch_extend_as(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters,
                                    int parity, WorkCounters* work, uint32_t* queues, const ExtendConfig& cfg,
                                    hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<COUNT, LDS_SCENE, THREADS>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<COUNT, LDS_SCENE>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_extend<COUNT, LDS_SCENE, THREADS>), dim3(cfg.grid), dim3(THREADS), cfg.lds_bytes, stream, sc, rc,
-                     cur, counters, parity, work, queues);
+  hipLaunchKernelGGL((k_extend<COUNT, LDS_SCENE>), dim3(cfg.grid), dim3(EXTEND_THREADS), cfg.lds_bytes, stream, sc, rc,
+                     cur, counters, parity, work, queues, cfg.refill_min, cfg.node_min);
   return hipGetLastError();
 }
 
@@ -1358,11 +1343,11 @@ hipError_t launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* c
                          WorkCounters* work, uint32_t* queues, bool count_work, const ExtendConfig& cfg,
                          hipStream_t stream) {
   if (cfg.lds_nodes) {
-    return count_work ? launch_extend_as<true, true, LDS_BLOCK_THREADS>(sc, rc, cur, counters, parity, work, queues, cfg, stream)
-                      : launch_extend_as<false, true, LDS_BLOCK_THREADS>(sc, rc, cur, counters, parity, work, queues, cfg, stream);
+    return count_work ? launch_extend_as<true, true>(sc, rc, cur, counters, parity, work, queues, cfg, stream)
+                      : launch_extend_as<false, true>(sc, rc, cur, counters, parity, work, queues, cfg, stream);
   }
-  return count_work ? launch_extend_as<true, false, BLOCK_THREADS>(sc, rc, cur, counters, parity, work, queues, cfg, stream)
-                    : launch_extend_as<false, false, BLOCK_THREADS>(sc, rc, cur, counters, parity, work, queues, cfg, stream);
+  return count_work ? launch_extend_as<true, false>(sc, rc, cur, counters, parity, work, queues, cfg, stream)
+                    : launch_extend_as<false, false>(sc, rc, cur, counters, parity, work, queues, cfg, stream);
 }
 
 void launch_shade(const DeviceScene& sc, const RenderConst& rc, const float4* cur, float4* next,

@@ -537,10 +537,20 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   rc.pool = pool;
   rc.region_cap = pool / N_REGIONS;
   rc.total_paths = total;
+  rc.n_groups = (uint32_t)(((uint64_t)p.width * p.height) / 64);
+  rc.group_stride = 1;
+  if (rc.n_groups > 1) {
+    // about 61 strides across the frame, the nearest one that is coprime to the group count
+    uint64_t stride = std::max<uint64_t>(1, rc.n_groups / 61);
+    stride = std::min<uint64_t>(stride, 0xFFFFFFFFull / rc.n_groups);
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+    while (stride > 1 && gcd(stride, rc.n_groups) != 1) --stride;
+    rc.group_stride = (uint32_t)stride;
+  }
 
   const bool count_work = (p.flags & MIRT_RENDER_COUNT_WORK) != 0;
   const bool time_kernels = (p.flags & MIRT_RENDER_TIME_KERNELS) != 0;
-  const ExtendConfig extend_cfg = plan_extend(scene->view, ctx->num_cu, pool);
+  const ExtendConfig extend_cfg = plan_extend(scene->view);
   if (std::getenv("MIRT_VERBOSE"))
     std::fprintf(stderr, "mirt: %zu prims, %u nodes, height %u; extend %s, %d x %d threads, %zu B LDS, stack %d; pool %u\n",
                  scene->n_prims, scene->view.n_nodes, scene->view.bvh_height,
@@ -605,6 +615,17 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
       stats->segments = w.segments;
       stats->nodes_visited = w.nodes;
       stats->prims_tested = w.prims;
+      if (std::getenv("MIRT_VERBOSE")) {
+        double lo = 1e30, hi = 0, sum = 0;
+        for (int b = 0; b < 256; ++b) {
+          const double ms = (double)w.block_busy[b] * 1e-5;
+          lo = std::min(lo, ms); hi = std::max(hi, ms); sum += ms;
+        }
+        std::fprintf(stderr, "mirt: extend blocks resident %.3f ms min, %.3f ms mean, %.3f ms max over the render\n", lo,
+                     sum / 256, hi);
+      }
+      stats->node_wave_steps = w.wave_nodes;
+      stats->prim_wave_steps = w.wave_prims;
       for (int k = 0; k < MIRT_PHASE_COUNT; ++k) stats->extend_phase_cycles[k] = w.cycles[k];
     }
     if (time_kernels) {

@@ -35,8 +35,8 @@ __host__ __device__ inline uint32_t make_material_word(uint32_t kind, uint32_t i
 // Traversal stack entries per lane (kept in LDS).  The host builder never
 // produces a tree taller than STACK_DEPTH - 2.
 constexpr int STACK_DEPTH = 32;
-constexpr int BLOCK_THREADS = 256;       // shade, trace, and extend with the BVH in global memory
-constexpr int LDS_BLOCK_THREADS = 1024;  // extend with the BVH staged in LDS: one block per CU
+constexpr int BLOCK_THREADS = 256;      // shade and trace
+constexpr int EXTEND_THREADS = 1024;    // extend: one block per region, a CU's worth of waves
 constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
 // BVH node, 64 bytes = 4 x float4:
@@ -130,28 +130,18 @@ struct DeviceScene {
 };
 
 // ---- the path pool ----------------------------------------------------------------
-// The pool is split into N_REGIONS regions so that no counter is shared by the
-// whole GPU: slots are dealt to regions in chunks of REGION_CHUNK (chunk c belongs
-// to region c % N_REGIONS), each region compacts its own survivors and owns four
-// material queues.  A wave always works on 64 consecutive slots of one chunk, so
-// every reservation it makes goes to one region's counters.
-constexpr uint32_t N_REGIONS = 64;
-constexpr uint32_t REGION_CHUNK = 1024;
-constexpr uint32_t POOL_GRANULE = N_REGIONS * REGION_CHUNK;
-
-__host__ __device__ inline uint32_t slot_region(uint32_t slot) { return (slot / REGION_CHUNK) % N_REGIONS; }
-__host__ __device__ inline uint32_t slot_local(uint32_t slot) {
-  return (slot / (REGION_CHUNK * N_REGIONS)) * REGION_CHUNK + (slot % REGION_CHUNK);
-}
-__host__ __device__ inline uint32_t region_slot(uint32_t region, uint32_t local) {
-  return ((local / REGION_CHUNK) * N_REGIONS + region) * REGION_CHUNK + (local % REGION_CHUNK);
-}
+// The pool is split into N_REGIONS equal regions of consecutive slots so that no counter is shared by
+// the whole GPU.  A region is the share of one extend block: the block keeps the region's queue
+// counters in LDS while it runs, shade compacts a region's survivors into the region's first slots
+// of the other buffer, and each region owns four material queues.
+constexpr uint32_t N_REGIONS = 256;
+constexpr uint32_t POOL_GRANULE = N_REGIONS * 64;  // a region is a whole number of waves
 
 // Per-iteration counters, double buffered by iteration parity; one 128-byte block per region.
 struct RegionCounters {
   uint32_t n_cur;       // paths the region carries over from the previous iteration (filled by shade)
   uint32_t pad0[3];
-  uint32_t queue_n[4];  // entries in the region's material queues (filled by extend)
+  uint32_t queue_n[4];  // entries in the region's material queues (written by the region's extend block)
   uint32_t pad1[24];
 };
 struct IterCounters {
@@ -165,9 +155,12 @@ struct WorkCounters {
   unsigned long long nodes;
   unsigned long long prims;
   unsigned long long pad;
+  unsigned long long wave_nodes;  // wave-wide turns spent on tree steps / on primitive tests
+  unsigned long long wave_prims;
   // shader-clock cycles summed over waves, per phase of extend (instrumented build only):
   // 0 load/generate, 1 inner-node loop, 2 primitive tests, 3 media, 4 write-back + binning, 5 whole kernel
   unsigned long long cycles[MIRT_PHASE_COUNT];
+  unsigned long long block_busy[256];  // 100 MHz ticks each extend block was resident, summed over launches
 };
 
 constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3, N_QUEUES = 4;
@@ -180,30 +173,35 @@ struct RenderConst {
   float background[3];
   uint32_t key0, key1;
   uint32_t pool;             // path records per buffer = N_REGIONS * region_cap
-  uint32_t region_cap;       // slots per region, a multiple of REGION_CHUNK
+  uint32_t region_cap;       // slots per region; region s owns slots [s * region_cap, (s + 1) * region_cap)
   uint64_t total_paths;      // width*height*samples_per_pixel of this call
+  // Order in which a pass walks the image: group j of 64 pixels (of the n_groups whole groups) is visited
+  // as number (j * group_stride) % n_groups; group_stride is coprime to n_groups and their product < 2^32.
+  uint32_t n_groups, group_stride;
 };
 
 // Path record, 64 bytes = 4 x float4:
 //   r0 = origin.xyz, time
 //   r1 = direction.xyz, bits(pixel = y*width + x, y up)
 //   r2 = throughput.rgb, bits(sample index << 8 | bounce)
-//   r3 = t of the closest hit, bits(hit ref), -, -     (the only part extend writes for a surviving path)
+//   r3 = t of the closest surface, bits(hit ref), -, -     (the only part extend writes for a surviving path)
 // Material queue q of region s holds slot numbers at queues[(q * N_REGIONS + s) * region_cap ...].
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
 constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
 // ---- launchers implemented in kernels.hip ------------------------------------
-// How extend is launched for a scene: with nodes, primitive records and wrapper chains staged in
-// LDS when they fit beside the traversal stacks of a 1024-thread block, else from global memory.
+// How extend is launched for a scene: one 1024-thread block per region, with nodes, primitive records and
+// wrapper chains staged in LDS when they fit beside the block's traversal stacks, else read from global memory.
 struct ExtendConfig {
   bool lds_nodes;
   int block;
   int grid;
   int stack_depth;
   size_t lds_bytes;
+  uint32_t refill_min;  // a wave hands in finished rays and fetches new ones once this many lanes have none
+  uint32_t node_min;    // a wave steps down the tree while this many lanes hold an inner node, else tests primitives
 };
-ExtendConfig plan_extend(const DeviceScene& sc, int num_cu, uint32_t pool);
+ExtendConfig plan_extend(const DeviceScene& sc);
 hipError_t launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters, int parity,
                          WorkCounters* work, uint32_t* queues, bool count_work, const ExtendConfig& cfg,
                          hipStream_t stream);
