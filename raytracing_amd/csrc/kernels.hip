@@ -220,10 +220,11 @@ __device__ __forceinline__ bool box_t(V3 mn, V3 mx, const Ray& r, float t_min, f
 
 // Tests the primitive whose record is number `index` against the world-space ray r: the ray goes
 // through the record's wrapper chain, then through the kind's own test.  Outputs the kind and, for
-// the caller's bookkeeping, the record's order rank and material word.
+// the caller's bookkeeping, the record's order rank and material word; `face` is the side hit of a box.
 template <int PSTRIDE>
 __device__ __forceinline__ bool record_t(const SceneTables& tb, uint32_t index, const Ray& r, float t_min, float t_max,
-                                         float& t, uint32_t& tag, uint32_t& order, uint32_t& material) {
+                                         float& t, uint32_t& tag, uint32_t& order, uint32_t& material,
+                                         uint32_t& face) {
   const float4* p = tb.prims + PSTRIDE * (size_t)index;
   const float4 qa = p[0], qc = p[2];
   const uint32_t chain_tag = __float_as_uint(qc.x);
@@ -244,9 +245,11 @@ __device__ __forceinline__ bool record_t(const SceneTables& tb, uint32_t index, 
     const bool ok = rect_t(__float_as_uint(qb.y), qa.x, qa.y, qa.z, qa.w, qb.x, lr, t_min, t_max, t, pa, pb);
     return ok && !(t != t);
   } else {
-    int face;
+    int side = 0;
     float pa, pb;
-    return box_t(xyz(qa), xyz(qb), lr, t_min, t_max, t, face, pa, pb);
+    const bool ok = box_t(xyz(qa), xyz(qb), lr, t_min, t_max, t, side, pa, pb);
+    face = (uint32_t)side;
+    return ok;
   }
 }
 
@@ -295,7 +298,7 @@ struct Walk {
   Ray r;
   V3 inv;
   float best_t;
-  uint32_t best_ref, best_order, best_material, cur, sp;
+  uint32_t best_ref, best_order, best_material, best_face, cur, sp;
 };
 
 __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root) {
@@ -306,6 +309,7 @@ __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root)
   w.best_ref = REF_NONE;
   w.best_order = 0;
   w.best_material = 0;
+  w.best_face = 0;
   w.cur = root;
   w.sp = 0;
 }
@@ -342,11 +346,12 @@ __device__ __forceinline__ void prim_step(Walk& w, const SceneTables& tb, float 
   using RC = RefCode<COMPACT>;
   const uint32_t index = w.cur & RC::MASK;
   float t;
-  uint32_t tag, order, material;
-  if (record_t<PSTRIDE>(tb, index, w.r, t_min, w.best_t, t, tag, order, material)) {
+  uint32_t tag, order, material, face = 0;
+  if (record_t<PSTRIDE>(tb, index, w.r, t_min, w.best_t, t, tag, order, material, face)) {
     // t == best_t: the later one in the reference's visiting order wins
     if (t < w.best_t || w.best_ref == REF_NONE || order > w.best_order) {
       w.best_t = t; w.best_ref = make_leaf(tag, index); w.best_material = material; w.best_order = order;
+      w.best_face = face;
     }
   }
   if ((w.cur >> RC::SHIFT) & 7u) w.cur += 1u - (1u << RC::SHIFT);  // one fewer left, starting one further
@@ -358,7 +363,8 @@ __device__ __forceinline__ void prim_step(Walk& w, const SceneTables& tb, float 
 template <bool COUNT, int PSTRIDE, bool COMPACT, class Slot>
 __device__ __forceinline__ void closest_surface(const SceneTables& tb, uint32_t root, const Ray& r,
                                                 float t_min, Slot* stack, uint32_t stride, uint32_t& best_ref,
-                                                float& best_t, uint32_t& best_material, Work& work) {
+                                                float& best_t, uint32_t& best_material, uint32_t& best_face,
+                                                Work& work) {
   Walk w;
   walk_begin(w, r, root);
   using RC = RefCode<COMPACT>;
@@ -374,6 +380,7 @@ __device__ __forceinline__ void closest_surface(const SceneTables& tb, uint32_t 
   best_ref = w.best_ref;
   best_t = w.best_t;
   best_material = w.best_material;
+  best_face = w.best_face;
 }
 
 // Both roots of the sphere quadratic (objects.rs:42-53), or false when the discriminant is negative.
@@ -447,9 +454,9 @@ __device__ __forceinline__ void closest_media(const DeviceScene& sc, const Scene
     } else {
       // boundary-only records are not staged in LDS: read them from global memory
       const SceneTables gt = global_tables(sc);
-      uint32_t tag, order, material;
-      if (!record_t<PRIM_QUADS>(gt, ref_index(med.boundary_ref), r, -kInf, kInf, h1, tag, order, material)) continue;
-      if (!record_t<PRIM_QUADS>(gt, ref_index(med.boundary_ref), r, h1 + 0.0001f, kInf, h2, tag, order, material)) continue;
+      uint32_t tag, order, material, face;
+      if (!record_t<PRIM_QUADS>(gt, ref_index(med.boundary_ref), r, -kInf, kInf, h1, tag, order, material, face)) continue;
+      if (!record_t<PRIM_QUADS>(gt, ref_index(med.boundary_ref), r, h1 + 0.0001f, kInf, h2, tag, order, material, face)) continue;
     }
     if (h1 < t_min) h1 = t_min;
     if (h2 > best_t) h2 = best_t;
@@ -470,6 +477,8 @@ __device__ __forceinline__ void closest_media(const DeviceScene& sc, const Scene
 struct Hit {
   V3 p, n;
   float t, u, v;
+  V3 on_sphere;    // sphere hits: the outward unit normal, from which (u, v) are worked out when a texture asks
+  bool sphere_uv;  // (u, v) still to be worked out from on_sphere
   bool front;
   uint32_t material_word;
 };
@@ -490,7 +499,8 @@ __device__ __forceinline__ void sphere_record(V3 center, float radius, const Ray
   h.t = t;
   h.p = ray_at(r, t);
   const V3 outward = (h.p - center) / radius;  // objects.rs:61-63
-  sphere_uv(outward, h.u, h.v);
+  h.on_sphere = outward;
+  h.sphere_uv = true;
   set_face(h, r, outward);
 }
 
@@ -506,8 +516,13 @@ __device__ __forceinline__ void rect_record(uint32_t axis, float a0, float a1, f
 // Rebuilds the record of the hit that closest_surface / closest_media found
 // at (ref, t), passing it through the wrappers inside-out as the nested
 // Hittable::hit calls of the reference do.
-__device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, const Ray& world_ray, float t_found) {
+// `face` is the side extend found for a box hit.
+__device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, const Ray& world_ray, float t_found,
+                                          uint32_t face) {
   Hit h;
+  h.sphere_uv = false;
+  h.on_sphere = v3(0.0f, 0.0f, 0.0f);
+  h.u = 0.0f; h.v = 0.0f;
   const uint32_t tag = ref_tag(ref), idx = ref_index(ref);
   uint32_t chain;
   if (tag == TAG_MEDIUM) {
@@ -556,16 +571,16 @@ __device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, c
   } else if (tag == TAG_RECT) {
     const float4 g0 = sc.prims[PRIM_QUADS * (size_t)idx], g1 = sc.prims[PRIM_QUADS * (size_t)idx + 1];
     const uint32_t axis = __float_as_uint(g1.y);
-    float t, pa = 0.0f, pb = 0.0f;
-    rect_t(axis, g0.x, g0.y, g0.z, g0.w, g1.x, r, kTMin, kInf, t, pa, pb);
+    // where the ray meets the rect's plane, as the hit test worked it out (objects.rs:212-213)
+    const float pa = axis == 2 ? r.o.y + t_found * r.d.y : r.o.x + t_found * r.d.x;
+    const float pb = axis == 0 ? r.o.y + t_found * r.d.y : r.o.z + t_found * r.d.z;
     rect_record(axis, g0.x, g0.y, g0.z, g0.w, r, t_found, pa, pb, h);
   } else {
     const float4 g0 = sc.prims[PRIM_QUADS * (size_t)idx], g1 = sc.prims[PRIM_QUADS * (size_t)idx + 1];
     const V3 mn = xyz(g0), mx = xyz(g1);
-    float t, pa = 0.0f, pb = 0.0f;
-    int face = 0;
-    box_t(mn, mx, r, kTMin, kInf, t, face, pa, pb);
-    const uint32_t axis = (uint32_t)face >> 1;
+    const uint32_t axis = face >> 1;  // the side of the box is one of its six rects (objects.rs:396-436)
+    const float pa = axis == 2 ? r.o.y + t_found * r.d.y : r.o.x + t_found * r.d.x;
+    const float pb = axis == 0 ? r.o.y + t_found * r.d.y : r.o.z + t_found * r.d.z;
     const float a0 = axis == 2 ? mn.y : mn.x, a1 = axis == 2 ? mx.y : mx.x;
     const float b0 = axis == 0 ? mn.y : mn.z, b1 = axis == 0 ? mx.y : mx.z;
     rect_record(axis, a0, a1, b0, b1, r, t_found, pa, pb, h);
@@ -636,7 +651,8 @@ __device__ __forceinline__ uint32_t f32_to_u32_sat(float v) {  // Rust `as u32`
   return (uint32_t)v;
 }
 
-__device__ __forceinline__ V3 texture_color(const DeviceScene& sc, uint32_t tex, float u, float v, V3 p) {
+__device__ __forceinline__ V3 texture_color(const DeviceScene& sc, uint32_t tex, const Hit& h) {
+  const V3 p = h.p;
   for (int depth = 0; depth < 8; ++depth) {
     const DTexture t = sc.textures[tex];
     if (t.kind == MIRT_TEX_SOLID) {
@@ -649,6 +665,8 @@ __device__ __forceinline__ V3 texture_color(const DeviceScene& sc, uint32_t tex,
       return v3(1.0f, 1.0f, 1.0f) * 0.5f * s;
     } else {  // texture.rs:101-122
       const DImage im = sc.images[t.index];
+      float u = h.u, v = h.v;
+      if (h.sphere_uv) sphere_uv(h.on_sphere, u, v);
       const float cu = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
       const float cv = 1.0f - (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
       uint32_t i = f32_to_u32_sat(cu * (float)im.width);
@@ -1018,7 +1036,7 @@ __global__ __launch_bounds__(EXTEND_THREADS) void k_extend(DeviceScene sc, Rende
           const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
           const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
           region_queues[(size_t)q * queue_stride + pos] = (uint32_t)(slot0 + slot);
-          cur[4 * (slot0 + slot) + 3] = make_float4(w.best_t, __uint_as_float(w.best_ref), 0.0f, 0.0f);
+          cur[4 * (slot0 + slot) + 3] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), 0.0f);
           slot = NO_SLOT;
           ++segments;
         }
@@ -1159,11 +1177,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderC
       if (ref == REF_NONE) {
         term = v3(rc.background[0], rc.background[1], rc.background[2]);  // renderer.rs:187-189
       } else {
-        const Hit h = hit_record(sc, ref, r, t);
+        const Hit h = hit_record(sc, ref, r, t, __float_as_uint(r3.z));
         const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
         Rng rng = rng_begin(pixel, sample, bounce, STAGE_SHADE, rc.key0, rc.key1);
         if (m.kind == MIRT_MAT_LAMBERTIAN) {  // material.rs:39-58, renderer.rs:166-183
-          const V3 att = texture_color(sc, m.texture, h.u, h.v, h.p);
+          const V3 att = texture_color(sc, m.texture, h);
           const Onb uvw = onb_from_w(h.n);
           V3 dir;
           float pdf;
@@ -1186,7 +1204,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderC
         } else if (m.kind == MIRT_MAT_METAL) {  // material.rs:75-91
           const V3 reflected = reflect(unit(r.d), h.n);
           const V3 fuzz = m.param * random_in_unit_sphere(rng);
-          const V3 att = texture_color(sc, m.texture, h.u, h.v, h.p);
+          const V3 att = texture_color(sc, m.texture, h);
           beta = beta * att;
           nr.o = h.p; nr.d = reflected + fuzz; nr.time = r.time;
           alive = true;
@@ -1201,7 +1219,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderC
           nr.o = h.p; nr.time = r.time;
           alive = true;
         } else if (m.kind == MIRT_MAT_DIFFUSE_LIGHT) {  // material.rs:151-158
-          if (h.front) term = texture_color(sc, m.texture, h.u, h.v, h.p);
+          if (h.front) term = texture_color(sc, m.texture, h);
         }
         // MIRT_MAT_ISOTROPIC: no scatter, no emission
       }
@@ -1264,11 +1282,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
   r.o = v3(in.origin[0], in.origin[1], in.origin[2]);
   r.d = v3(in.direction[0], in.direction[1], in.direction[2]);
   r.time = in.time;
-  uint32_t ref, material;
+  uint32_t ref, material, face;
   float t;
   Work work{};
   const SceneTables tb = global_tables(sc);
-  closest_surface<false, (int)PRIM_QUADS, false>(tb, sc.root_ref, r, kTMin, stack, BLOCK_THREADS, ref, t, material, work);
+  closest_surface<false, (int)PRIM_QUADS, false>(tb, sc.root_ref, r, kTMin, stack, BLOCK_THREADS, ref, t, material, face,
+                                                 work);
   if (sc.n_media != 0) {
     Rng rng = rng_begin((uint32_t)i, 0, 0, STAGE_MEDIA, key0, key1);
     closest_media(sc, tb, media, r, kTMin, rng, ref, t, material);

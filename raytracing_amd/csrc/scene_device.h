@@ -184,7 +184,8 @@ struct RenderConst {
 //   r0 = origin.xyz, time
 //   r1 = direction.xyz, bits(pixel = y*width + x, y up)
 //   r2 = throughput.rgb, bits(sample index << 8 | bounce)
-//   r3 = t of the closest surface, bits(hit ref), -, -     (the only part extend writes for a surviving path)
+//   r3 = t of the closest surface, bits(hit ref), bits(side of a box hit), -     (the only part extend writes
+//        for a surviving path)
 // Material queue q of region s holds slot numbers at queues[(q * N_REGIONS + s) * region_cap ...].
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
 constexpr uint32_t MAX_DEPTH_LIMIT = 255;
