@@ -151,25 +151,33 @@ def main():
         p = ws["prims_tested"] / max(1, ws["segments"])    # primitive tests per segment
         roofline = None
         valu = None
-        if kernel_launches[R.MIRT_KERNEL_EXTEND]:
-            # extend, per segment: path record in (64 B) or out for a new path, ray+hit write-back (32 B),
-            # queue entry (4 B), one 64-B node per node visit, one 32-B primitive record per test
-            bytes_per_segment = 64 + 32 + 4 + 64 * n + 32 * p
+        if kernel_launches[R.MIRT_KERNEL_RENDER]:
+            # One launch of k_render traces a whole step.  Algorithmic bytes per segment:
+            #   walk  : ray in (32 B), hit out (16 B), queue entry out (4 B), a 64-B node per tree step,
+            #           a 48-B primitive record per primitive test
+            #   shade : queue entry in (4 B), path record in (64 B), 48 B out for the paths that go on
+            #           (s - 1 of every s segments) or 12 B of radiance for the one that ends
+            #   start : 48 B of path record per camera path (1 of every s segments)
+            bytes_per_segment = 32 + 16 + 4 + 64 * n + 48 * p + 4 + 64 + 48 * (s - 1) / s + (12 + 48) / s
             my_segments = s * a.width * a.height * count * a.steps
-            ext_s = kernel_ms[R.MIRT_KERNEL_EXTEND] / 1e3
-            achieved = my_segments * bytes_per_segment / ext_s / 1e9
-            roofline = {"kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            ker_s = kernel_ms[R.MIRT_KERNEL_RENDER] / 1e3
+            achieved = my_segments * bytes_per_segment / ker_s / 1e9
+            cyc = ws["phase_cycles"]
+            names = ["start_fetch", "tree_steps", "primitive_tests", "shade", "hand_in", "total"]
+            roofline = {"kernel": "k_render", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "avg_launch_ms": kernel_ms[R.MIRT_KERNEL_EXTEND] / kernel_launches[R.MIRT_KERNEL_EXTEND],
-                        "launches": kernel_launches[R.MIRT_KERNEL_EXTEND],
+                        "avg_launch_ms": kernel_ms[R.MIRT_KERNEL_RENDER] / kernel_launches[R.MIRT_KERNEL_RENDER],
+                        "launches": kernel_launches[R.MIRT_KERNEL_RENDER],
                         "bytes_per_segment": bytes_per_segment,
-                        "segments_per_launch": my_segments / kernel_launches[R.MIRT_KERNEL_EXTEND],
+                        "segments_per_launch": my_segments / kernel_launches[R.MIRT_KERNEL_RENDER],
                         "segments_per_sample": s, "nodes_per_segment": n, "prims_per_segment": p,
-                        "shade_avg_launch_ms": kernel_ms[R.MIRT_KERNEL_SHADE] / max(1, kernel_launches[R.MIRT_KERNEL_SHADE])}
-            # two padded slab tests per node (2 x 32 flops), ~26 flops per primitive test
+                        "lanes_at_work": {"tree_steps": ws["nodes_visited"] / max(1, 64 * ws["node_wave_steps"]),
+                                          "primitive_tests": ws["prims_tested"] / max(1, 64 * ws["prim_wave_steps"])},
+                        "wave_time_share": {k: cyc[i] / max(1, cyc[5]) for i, k in enumerate(names[:5])}}
+            # two padded slab tests per tree step (2 x 32 flops), ~26 flops per primitive test; shading not counted
             flops_per_segment = 64 * n + 26 * p
-            tf = my_segments * flops_per_segment / ext_s / 1e12
-            valu = {"kernel": "k_extend", "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            tf = my_segments * flops_per_segment / ker_s / 1e12
+            valu = {"kernel": "k_render", "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tf / VALU_PEAK_TFLOPS, "flops_per_segment": flops_per_segment}
         result = {
             "metric": "Msamples/s on final_scene 1080p", "value": value, "unit": "Msamples/s", "n_gpus": world,
@@ -178,7 +186,7 @@ def main():
             "config": {"workload": f"{a.scene} {a.width}x{a.height}, {a.spp} spp, depth {depth}",
                        "sharding": f"sample ranges over {world} GPU(s), RCCL sum-reduce of the f32 image" if world > 1
                        else "single GPU", "path_pool": ws["path_pool"], "seed": a.seed,
-                       "iterations_per_step": iterations / max(1, a.steps)},
+                       "rounds_per_step": iterations / max(1, a.steps)},
             "roofline": roofline, "roofline_valu": valu,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -269,9 +269,11 @@ typedef struct mirt_render_params {
   uint32_t flags;             /* MIRT_RENDER_* */
 } mirt_render_params;
 
-enum { MIRT_KERNEL_EXTEND = 0, MIRT_KERNEL_SHADE = 1, MIRT_KERNEL_RESOLVE = 2, MIRT_KERNEL_COUNT = 4 };
-/* phases of the extend kernel timed by MIRT_RENDER_COUNT_WORK */
-enum { MIRT_PHASE_LOAD = 0, MIRT_PHASE_NODES = 1, MIRT_PHASE_PRIMS = 2, MIRT_PHASE_MEDIA = 3, MIRT_PHASE_WRITE = 4,
+/* MIRT_KERNEL_RENDER: the one kernel that traces a whole mirt_render_accumulate call */
+enum { MIRT_KERNEL_RENDER = 0, MIRT_KERNEL_RESOLVE = 1, MIRT_KERNEL_COUNT = 4 };
+/* phases of the render kernel timed by MIRT_RENDER_COUNT_WORK: starting camera paths and fetching rays,
+ * steps down the BVH, primitive tests, shading, handing finished rays to the material queues, whole kernel */
+enum { MIRT_PHASE_LOAD = 0, MIRT_PHASE_NODES = 1, MIRT_PHASE_PRIMS = 2, MIRT_PHASE_SHADE = 3, MIRT_PHASE_WRITE = 4,
        MIRT_PHASE_TOTAL = 5, MIRT_PHASE_COUNT = 6 };
 
 typedef struct mirt_stats {
@@ -280,11 +282,11 @@ typedef struct mirt_stats {
   uint64_t segments;      /* path segments traced (closest-hit queries) */
   uint64_t nodes_visited; /* BVH nodes fetched   (MIRT_RENDER_COUNT_WORK) */
   uint64_t prims_tested;  /* primitive tests     (MIRT_RENDER_COUNT_WORK) */
-  uint32_t iterations;    /* extend/shade rounds */
+  uint32_t iterations;    /* most start/walk/shade rounds any one region of the pool went through */
   uint32_t path_pool;
   double kernel_ms[MIRT_KERNEL_COUNT];         /* summed device time per kernel (MIRT_RENDER_TIME_KERNELS) */
   uint32_t kernel_launches[MIRT_KERNEL_COUNT];
-  uint64_t extend_phase_cycles[MIRT_PHASE_COUNT]; /* shader-clock cycles summed over waves (MIRT_RENDER_COUNT_WORK) */
+  uint64_t phase_cycles[MIRT_PHASE_COUNT]; /* shader-clock cycles summed over waves (MIRT_RENDER_COUNT_WORK) */
   uint64_t node_wave_steps; /* wave-wide turns spent stepping down the tree: nodes_visited / (64 * this) is the
                                share of lanes doing useful work in them   (MIRT_RENDER_COUNT_WORK) */
   uint64_t prim_wave_steps; /* the same for primitive tests */

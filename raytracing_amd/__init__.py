@@ -23,7 +23,7 @@ LIBEXAMPLES = PKG_DIR / "librt_examples.so"
 
 MIRT_RENDER_COUNT_WORK = 1
 MIRT_RENDER_TIME_KERNELS = 2
-MIRT_KERNEL_EXTEND, MIRT_KERNEL_SHADE, MIRT_KERNEL_RESOLVE, MIRT_KERNEL_COUNT = 0, 1, 2, 4
+MIRT_KERNEL_RENDER, MIRT_KERNEL_RESOLVE, MIRT_KERNEL_COUNT = 0, 1, 4
 
 
 class MirtError(RuntimeError):
@@ -129,7 +129,7 @@ class Stats(C.Structure):
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64), ("iterations", C.c_uint32),
                 ("path_pool", C.c_uint32), ("kernel_ms", C.c_double * MIRT_KERNEL_COUNT),
                 ("kernel_launches", C.c_uint32 * MIRT_KERNEL_COUNT),
-                ("extend_phase_cycles", C.c_uint64 * 6),
+                ("phase_cycles", C.c_uint64 * 6),
                 ("node_wave_steps", C.c_uint64), ("prim_wave_steps", C.c_uint64)]
 
     def as_dict(self):
@@ -138,7 +138,7 @@ class Stats(C.Structure):
                 "iterations": int(self.iterations), "path_pool": int(self.path_pool),
                 "kernel_ms": [float(x) for x in self.kernel_ms],
                 "kernel_launches": [int(x) for x in self.kernel_launches],
-                "extend_phase_cycles": [int(x) for x in self.extend_phase_cycles],
+                "phase_cycles": [int(x) for x in self.phase_cycles],
                 "node_wave_steps": int(self.node_wave_steps), "prim_wave_steps": int(self.prim_wave_steps)}
 
 

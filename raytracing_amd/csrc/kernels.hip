@@ -125,10 +125,23 @@ struct SceneTables {
   const uint2* chains;
   const float4* chain_ops;
 };
-__device__ __forceinline__ SceneTables global_tables(const DeviceScene& sc) {
-  return SceneTables{sc.nodes, sc.prims, sc.chains, sc.chain_ops};
-}
-__device__ __forceinline__ uint2 prim_ids(const DeviceScene& sc, uint32_t ref) { return sc.prim_ids[ref_index(ref)]; }
+// What shading reads besides the geometry: materials, textures and their tables, the lights to sample.
+struct ShadeTables {
+  const DMaterial* materials;
+  const DTexture* textures;
+  const float4* perlin_vec;     // 256 per table (xyz, -)
+  const uint32_t* perlin_perm;  // 768 per table: perm_x, perm_y, perm_z
+  const DImage* images;
+  const uint8_t* image_data;
+  const DLight* lights;
+  const uint2* light_groups;  // (first_light, n_lights)
+  uint32_t lights_mode, n_lights, n_light_groups;
+};
+// Both from a scene description in any address space (kernel argument or constant memory).
+#define MIRT_GLOBAL_TABLES(sc) SceneTables{(sc).nodes, (sc).prims, (sc).chains, (sc).chain_ops}
+#define MIRT_SHADE_TABLES(sc)                                                                                   \
+  ShadeTables{(sc).materials, (sc).textures, (sc).perlin_vec, (sc).perlin_perm, (sc).images, (sc).image_data, \
+              (sc).lights,    (sc).light_groups, (sc).lights_mode, (sc).n_lights, (sc).n_light_groups}
 
 // ---- wrappers (transforms.rs) --------------------------------------------------
 // Applies the wrappers of a chain to a ray, outermost first (transforms.rs:16, 82-91).
@@ -408,15 +421,16 @@ struct MediumEntry {
   uint32_t pad[3];
 };
 
-__device__ __forceinline__ void stage_media(const DeviceScene& sc, MediumEntry* table) {
-  if (threadIdx.x < sc.n_media) {
-    const DMedium med = sc.media[threadIdx.x];
+__device__ __forceinline__ void stage_media(uint32_t n_media, const DMedium* media, const float4* prims,
+                                            MediumEntry* table) {
+  if (threadIdx.x < n_media) {
+    const DMedium med = media[threadIdx.x];
     MediumEntry e;
     e.boundary = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     e.boundary_ref = med.boundary_ref;
     e.boundary_chain = 0;
     if (ref_tag(med.boundary_ref) == TAG_SPHERE) {
-      const float4* p = sc.prims + PRIM_QUADS * (size_t)ref_index(med.boundary_ref);
+      const float4* p = prims + PRIM_QUADS * (size_t)ref_index(med.boundary_ref);
       e.boundary = p[0];
       e.boundary_chain = __float_as_uint(p[2].x) >> 2;
     }
@@ -432,10 +446,11 @@ __device__ __forceinline__ void stage_media(const DeviceScene& sc, MediumEntry* 
 // Medium m reads draw m of the STAGE_MEDIA stream, so the order media are
 // visited in does not matter; an accepted medium hit replaces the current
 // closest hit exactly as World::hit does with its shrinking t_max.
-__device__ __forceinline__ void closest_media(const DeviceScene& sc, const SceneTables& tb, const MediumEntry* table,
-                                              const Ray& r, float t_min, Rng& rng, uint32_t& best_ref, float& best_t,
-                                              uint32_t& best_material) {
-  for (uint32_t m = 0; m < sc.n_media; ++m) {
+// `tb` serves the wrapper chains (possibly from LDS), `gt` the records in global memory.
+__device__ __forceinline__ void closest_media(uint32_t n_media, const SceneTables& tb, const SceneTables& gt,
+                                              const MediumEntry* table, const Ray& r, float t_min, Rng& rng,
+                                              uint32_t& best_ref, float& best_t, uint32_t& best_material) {
+  for (uint32_t m = 0; m < n_media; ++m) {
     const MediumEntry med = table[m];
     float h1, h2;
     if (ref_tag(med.boundary_ref) == TAG_SPHERE) {
@@ -453,7 +468,6 @@ __device__ __forceinline__ void closest_media(const DeviceScene& sc, const Scene
       else continue;
     } else {
       // boundary-only records are not staged in LDS: read them from global memory
-      const SceneTables gt = global_tables(sc);
       uint32_t tag, order, material, face;
       if (!record_t<PRIM_QUADS>(gt, ref_index(med.boundary_ref), r, -kInf, kInf, h1, tag, order, material, face)) continue;
       if (!record_t<PRIM_QUADS>(gt, ref_index(med.boundary_ref), r, h1 + 0.0001f, kInf, h2, tag, order, material, face)) continue;
@@ -517,19 +531,21 @@ __device__ __forceinline__ void rect_record(uint32_t axis, float a0, float a1, f
 // at (ref, t), passing it through the wrappers inside-out as the nested
 // Hittable::hit calls of the reference do.
 // `face` is the side extend found for a box hit.
-__device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, const Ray& world_ray, float t_found,
-                                          uint32_t face) {
+template <int PSTRIDE>
+__device__ __forceinline__ Hit hit_record(const SceneTables& tb, const MediumEntry* media, uint32_t ref,
+                                          const Ray& world_ray, float t_found, uint32_t face) {
   Hit h;
   h.sphere_uv = false;
   h.on_sphere = v3(0.0f, 0.0f, 0.0f);
   h.u = 0.0f; h.v = 0.0f;
   const uint32_t tag = ref_tag(ref), idx = ref_index(ref);
   uint32_t chain;
+  const float4* rec = tb.prims + PSTRIDE * (size_t)idx;  // not read for a medium
   if (tag == TAG_MEDIUM) {
-    chain = sc.media[idx].chain;
-    h.material_word = sc.media[idx].material_word;
+    chain = media[idx].chain;
+    h.material_word = media[idx].material_word;
   } else {
-    const float4 qc = sc.prims[PRIM_QUADS * (size_t)idx + 2];
+    const float4 qc = rec[2];
     chain = __float_as_uint(qc.x) >> 2;
     h.material_word = __float_as_uint(qc.z);
   }
@@ -538,9 +554,9 @@ __device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, c
   Ray r = world_ray;
   uint2 c = make_uint2(0, 0);
   if (chain != 0) {
-    c = sc.chains[chain];
+    c = tb.chains[chain];
     for (uint32_t k = 0; k < c.y && k < MIRT_MAX_CHAIN_OPS; ++k) {
-      const float4 op = sc.chain_ops[c.x + k];
+      const float4 op = tb.chain_ops[c.x + k];
       const uint32_t kind = __float_as_uint(op.x);
       if (kind == MIRT_OP_TRANSLATE) {
         r.o = r.o - v3(op.y, op.z, op.w);
@@ -562,21 +578,20 @@ __device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, c
     h.u = 0.0f; h.v = 0.0f;
     h.front = true;
   } else if (tag == TAG_SPHERE) {
-    const float4 g = sc.prims[PRIM_QUADS * (size_t)idx];
+    const float4 g = rec[0];
     sphere_record(xyz(g), g.w, r, t_found, h);
   } else if (tag == TAG_MOVING_SPHERE) {
-    const float4* mp = sc.prims + PRIM_QUADS * (size_t)idx;
-    const float4 m0 = mp[0], m1 = mp[1];
-    sphere_record(moving_center(m0, m1, mp[2].w, r.time), m0.w, r, t_found, h);
+    const float4 m0 = rec[0], m1 = rec[1];
+    sphere_record(moving_center(m0, m1, rec[2].w, r.time), m0.w, r, t_found, h);
   } else if (tag == TAG_RECT) {
-    const float4 g0 = sc.prims[PRIM_QUADS * (size_t)idx], g1 = sc.prims[PRIM_QUADS * (size_t)idx + 1];
+    const float4 g0 = rec[0], g1 = rec[1];
     const uint32_t axis = __float_as_uint(g1.y);
     // where the ray meets the rect's plane, as the hit test worked it out (objects.rs:212-213)
     const float pa = axis == 2 ? r.o.y + t_found * r.d.y : r.o.x + t_found * r.d.x;
     const float pb = axis == 0 ? r.o.y + t_found * r.d.y : r.o.z + t_found * r.d.z;
     rect_record(axis, g0.x, g0.y, g0.z, g0.w, r, t_found, pa, pb, h);
   } else {
-    const float4 g0 = sc.prims[PRIM_QUADS * (size_t)idx], g1 = sc.prims[PRIM_QUADS * (size_t)idx + 1];
+    const float4 g0 = rec[0], g1 = rec[1];
     const V3 mn = xyz(g0), mx = xyz(g1);
     const uint32_t axis = face >> 1;  // the side of the box is one of its six rects (objects.rs:396-436)
     const float pa = axis == 2 ? r.o.y + t_found * r.d.y : r.o.x + t_found * r.d.x;
@@ -587,7 +602,7 @@ __device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, c
   }
   if (chain != 0) {
     for (int k = (int)c.y - 1; k >= 0; --k) {
-      const float4 op = sc.chain_ops[c.x + k];
+      const float4 op = tb.chain_ops[c.x + k];
       const uint32_t kind = __float_as_uint(op.x);
       const V3 d = dir_at[k < MIRT_MAX_CHAIN_OPS ? k : 0];
       if (kind == MIRT_OP_TRANSLATE) {  // transforms.rs:18-19
@@ -612,7 +627,7 @@ __device__ __forceinline__ Hit hit_record(const DeviceScene& sc, uint32_t ref, c
 }
 
 // ---- textures (texture.rs, perlin.rs) ----------------------------------------------
-__device__ __forceinline__ float perlin_noise(const DeviceScene& sc, uint32_t table, V3 p) {  // perlin.rs:26-48,75-93
+__device__ __forceinline__ float perlin_noise(const ShadeTables& sc, uint32_t table, V3 p) {  // perlin.rs:26-48,75-93
   const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
   const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
   const int i = (int)fx, j = (int)fy, k = (int)fz;
@@ -638,7 +653,7 @@ __device__ __forceinline__ float perlin_noise(const DeviceScene& sc, uint32_t ta
   return accum;
 }
 
-__device__ __forceinline__ float perlin_turb2(const DeviceScene& sc, uint32_t table, V3 p) {  // perlin.rs:50-60, depth 2
+__device__ __forceinline__ float perlin_turb2(const ShadeTables& sc, uint32_t table, V3 p) {  // perlin.rs:50-60, depth 2
   float accum = 0.0f;
   accum += 1.0f * perlin_noise(sc, table, p);
   accum += 0.5f * perlin_noise(sc, table, p * 2.0f);
@@ -651,7 +666,7 @@ __device__ __forceinline__ uint32_t f32_to_u32_sat(float v) {  // Rust `as u32`
   return (uint32_t)v;
 }
 
-__device__ __forceinline__ V3 texture_color(const DeviceScene& sc, uint32_t tex, const Hit& h) {
+__device__ __forceinline__ V3 texture_color(const ShadeTables& sc, uint32_t tex, const Hit& h) {
   const V3 p = h.p;
   for (int depth = 0; depth < 8; ++depth) {
     const DTexture t = sc.textures[tex];
@@ -778,14 +793,14 @@ __device__ __forceinline__ V3 light_random(const DLight& l, V3 origin, Rng& rng)
   return v3(1.0f, 0.0f, 0.0f);
 }
 // HittablePdf over the `lights` argument (pdf.rs:56-67, world.rs:100-117)
-__device__ __forceinline__ float lights_pdf_value(const DeviceScene& sc, V3 origin, V3 dir) {
+__device__ __forceinline__ float lights_pdf_value(const ShadeTables& sc, V3 origin, V3 dir) {
   if (sc.lights_mode == MIRT_LIGHTS_OBJECT) return light_pdf_value(sc.lights[0], origin, dir);
   const float weight = 1.0f / (float)sc.n_lights;
   float sum = 0.0f;
   for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf_value(sc.lights[i], origin, dir);
   return sum;
 }
-__device__ __forceinline__ V3 lights_random(const DeviceScene& sc, V3 origin, Rng& rng) {
+__device__ __forceinline__ V3 lights_random(const ShadeTables& sc, V3 origin, Rng& rng) {
   if (sc.lights_mode == MIRT_LIGHTS_OBJECT) return light_random(sc.lights[0], origin, rng);
   uint32_t g = (uint32_t)(rng_next(rng) * (float)sc.n_light_groups);
   if (g >= sc.n_light_groups) g = sc.n_light_groups - 1;
@@ -849,230 +864,439 @@ __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& to
   return inc - v;
 }
 
-// ---- extend -----------------------------------------------------------------------
+// ---- render -----------------------------------------------------------------------
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
-// Block-shared bookkeeping of extend, filled by the first wave.
-struct ExtendShared {
-  uint32_t n_surv;     // the region carries survivors in its local slots [0, n_surv)
-  uint32_t n_fresh;    // camera paths started in the region this iteration, in the slots after the survivors
-  uint32_t first_new;  // number of the region's first new path among this iteration's new paths
-  uint32_t next_work;  // next local slot to hand out
-  uint32_t queue_n[N_QUEUES];
+// Block-shared bookkeeping of one region's loop, written by thread 0 between barriers.
+struct RenderShared {
+  uint32_t n_fresh;                     // camera paths started this round, in the slots after the survivors
+  uint32_t first_new_lo, first_new_hi;  // number of the first of them among the render's paths
+  uint32_t next_work;                   // next slot to hand out to the walk
+  uint32_t queue_n[N_QUEUES];           // entries in the region's material queues
+  uint32_t n_next;                      // survivors written to the other buffer so far
+  uint32_t pad[3];
+  MediumEntry media[MIRT_MAX_MEDIA];
+};
+static_assert(sizeof(RenderShared) % 16 == 0, "keeps the node array 16-byte aligned");
+
+// The launch arguments live in device memory.  Each phase of the kernel reads what it needs through this:
+// the empty asm hides where the address came from, so the compiler cannot move those loads up to the start of
+// the kernel and hold dozens of scalar registers across phases that never use them; the constant address
+// space tells it the memory does not change, so the reads go through the scalar unit.
+typedef const __attribute__((address_space(4))) RenderArgs* ConstArgs;
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ ConstArgs pinned(const RenderArgs* p) {
+  // (a function's arguments arrive in vector registers even when every lane holds the same value)
+  unsigned long long v = ((unsigned long long)uniform((uint32_t)((unsigned long long)p >> 32)) << 32) |
+                         uniform((uint32_t)(unsigned long long)p);
+  asm volatile("" : "+s"(v));
+  return (ConstArgs)v;
+}
+
+// Dynamic shared memory of the render kernel: [RenderShared][nodes][48-byte primitive records][chain ops]
+// [chains][stack] when the scene is staged (LDS_SCENE), else [RenderShared][stack].
+template <bool LDS_SCENE>
+struct RenderLds {
+  using Slot = typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type;
+  float4* nodes;
+  float4* prims;
+  float4* ops;
+  uint2* chains;
+  Slot* stack;  // this thread's column; rows are RENDER_THREADS entries apart
+  __device__ __forceinline__ RenderLds(float4* smem, ConstArgs A) {
+    float4* after = smem + sizeof(RenderShared) / 16;
+    nodes = after;
+    prims = nodes + (LDS_SCENE ? A->sc.n_nodes * 4u : 0u);
+    ops = prims + (LDS_SCENE ? A->sc.n_prims * PRIM_QUADS_LDS : 0u);
+    chains = reinterpret_cast<uint2*>(ops + (LDS_SCENE ? A->sc.n_chain_ops : 0u));
+    // chains are 8 bytes each: round up so the stack starts on a 16-byte boundary
+    stack = reinterpret_cast<Slot*>(chains + (LDS_SCENE ? ((A->sc.n_chains + 1u) & ~1u) : 0u)) + threadIdx.x;
+  }
+  // the tables the walk and the shading read the scene's geometry from
+  __device__ __forceinline__ SceneTables tables(ConstArgs A) const {
+    if (LDS_SCENE) return SceneTables{nodes, prims, chains, ops};
+    return MIRT_GLOBAL_TABLES(A->sc);
+  }
 };
 
-// One launch advances every live path by one segment; block s does region s.  Camera paths are started
-// in the region's free slots, then each live slot's ray finds its closest surface and the slot number
-// goes into the region's queue for the material hit (constant media get their chance in shade).  The
-// walk is the divergent part: lanes whose ray has finished pull the next ray of the region instead of
-// waiting for the slowest lane of the wave.
-//
-// LDS_SCENE: the block first stages the whole scene the traversal touches in LDS -- dynamic shared memory
-// holds [bookkeeping][nodes][48-byte primitive records][chain ops][chains][stack] -- so the walk never
-// waits on global memory; otherwise those tables are read from global memory and LDS holds the stack only.
+// The three phases of a round are separate functions so that each gets registers of its own: the walk needs
+// few and must not spill, shading needs many.
+
+// Starts n_fresh camera paths (renderer.rs:215-218, camera.rs:57-68) in the region's slots after the survivors.
+template <bool COUNT>
+__device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint32_t n_surv, uint32_t n_fresh,
+                                         uint64_t first_new) {
+  constexpr int THREADS = RENDER_THREADS;
+  ConstArgs A = pinned(args);
+  odd = uniform(odd) != 0;
+  n_surv = uniform(n_surv);
+  n_fresh = uniform(n_fresh);
+  first_new = ((uint64_t)uniform((uint32_t)(first_new >> 32)) << 32) | uniform((uint32_t)first_new);
+  const uint32_t region = blockIdx.x;
+  const uint32_t width = A->rc.width, height = A->rc.height, first_sample = A->rc.first_sample;
+  const uint32_t key0 = A->rc.key0, key1 = A->rc.key1;
+  const uint32_t n_groups = A->rc.n_groups, group_stride = A->rc.group_stride;
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * A->rc.region_cap;
+  const V3 cu = v3(A->rc.cam.u[0], A->rc.cam.u[1], A->rc.cam.u[2]);
+  const V3 cv = v3(A->rc.cam.v[0], A->rc.cam.v[1], A->rc.cam.v[2]);
+  const V3 origin = v3(A->rc.cam.origin[0], A->rc.cam.origin[1], A->rc.cam.origin[2]);
+  const V3 llc = v3(A->rc.cam.lower_left_corner[0], A->rc.cam.lower_left_corner[1], A->rc.cam.lower_left_corner[2]);
+  const V3 hor = v3(A->rc.cam.horizontal[0], A->rc.cam.horizontal[1], A->rc.cam.horizontal[2]);
+  const V3 ver = v3(A->rc.cam.vertical[0], A->rc.cam.vertical[1], A->rc.cam.vertical[2]);
+  const float lens_radius = A->rc.cam.lens_radius, time0 = A->rc.cam.time0, time1 = A->rc.cam.time1;
+  const uint32_t pixels = width * height;
+  for (uint32_t k = threadIdx.x; k < n_fresh; k += THREADS) {
+    const size_t i = n_surv + k;
+    const uint64_t g = first_new + k;
+    const uint32_t pass = (uint32_t)(g / pixels);
+    uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
+    // Consecutive groups of 64 paths start far apart in the image, so that every region's new paths are
+    // a sample of the whole frame and the regions cost about the same to trace.
+    const uint32_t group = in_pass >> 6;
+    if (group < n_groups) in_pass = (((group * group_stride) % n_groups) << 6) | (in_pass & 63u);
+    uint32_t x, y;
+    pixel_of(in_pass, width, height, x, y);
+    const uint32_t pixel = y * width + x;
+    const uint32_t sample = first_sample + pass;
+    Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, key0, key1);
+    const float u = ((float)x + rng_next(rng)) / (float)(width - 1);
+    const float v = ((float)y + rng_next(rng)) / (float)(height - 1);
+    V3 disk;
+    for (;;) {  // vec3.rs:53-60
+      const float dx = rng_range(rng, -1.0f, 1.0f);
+      const float dy = rng_range(rng, -1.0f, 1.0f);
+      disk = v3(dx, dy, 0.0f);
+      if (len2(disk) < 1.0f) break;
+    }
+    const V3 rd = lens_radius * disk;
+    const V3 offset = cu * rd.x + cv * rd.y;
+    const V3 d = llc + u * hor + v * ver - origin - offset;
+    const V3 o = origin + offset;
+    const float time = rng_range(rng, time0, time1);
+    cur[4 * i] = make_float4(o.x, o.y, o.z, time);
+    cur[4 * i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
+    cur[4 * i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
+  }
+}
+
+// Finds the closest surface of every live ray of the region (slots [0, total)) and puts each slot into the
+// queue of the material hit.  Lanes whose ray has finished pull the region's next ray instead of waiting for
+// the slowest lane of the wave.
 template <bool COUNT, bool LDS_SCENE>
-__global__ __launch_bounds__(EXTEND_THREADS) void k_extend(DeviceScene sc, RenderConst rc, float4* __restrict__ cur,
-                                                           IterCounters* counters, int parity, WorkCounters* work_out,
-                                                           uint32_t* __restrict__ queues, uint32_t refill_min,
-                                                           uint32_t node_min) {
-  constexpr int THREADS = EXTEND_THREADS;
+__device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_t total, Work* work_out,
+                                       uint32_t* segments_out) {
+  constexpr int THREADS = RENDER_THREADS;
   extern __shared__ float4 smem[];
-  static_assert(sizeof(ExtendShared) % 16 == 0, "keeps the node array 16-byte aligned");
-  static_assert(N_REGIONS == 256, "the first wave looks after four regions per lane");
-  ExtendShared& sh = *reinterpret_cast<ExtendShared*>(smem);
-  float4* after = smem + sizeof(ExtendShared) / 16;
-  SceneTables tb = global_tables(sc);
-  long long block_begin = 0;
-  if (COUNT) block_begin = wall_clock64();
-  using Slot = typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type;
+  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
   using RC = RefCode<LDS_SCENE>;
   constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
-  Slot* stack = reinterpret_cast<Slot*>(after) + threadIdx.x;
-  if (LDS_SCENE) {
-    const uint32_t n_node_quads = sc.n_nodes * 4u;
-    const uint32_t n_prim_quads = sc.n_prims * PRIM_QUADS_LDS;
-    float4* l_nodes = after;
-    float4* l_prims = l_nodes + n_node_quads;
-    float4* l_ops = l_prims + n_prim_quads;
-    uint2* l_chains = reinterpret_cast<uint2*>(l_ops + sc.n_chain_ops);
-    for (uint32_t k = threadIdx.x; k < n_node_quads; k += THREADS) {
-      float4 q = sc.nodes[k];
-      if ((k & 3u) < 2u) q.w = __uint_as_float(RefCode<true>::encode(__float_as_uint(q.w)));  // child refs
-      l_nodes[k] = q;
-    }
-    for (uint32_t k = threadIdx.x; k < n_prim_quads; k += THREADS)
-      l_prims[k] = sc.prims[(k / PRIM_QUADS_LDS) * PRIM_QUADS + (k % PRIM_QUADS_LDS)];
-    for (uint32_t k = threadIdx.x; k < sc.n_chain_ops; k += THREADS) l_ops[k] = sc.chain_ops[k];
-    for (uint32_t k = threadIdx.x; k < sc.n_chains; k += THREADS) l_chains[k] = sc.chains[k];
-    tb = SceneTables{l_nodes, l_prims, l_chains, l_ops};
-    // chains are 8 bytes each: round up so the stack starts on a 16-byte boundary
-    stack = reinterpret_cast<Slot*>(l_chains + ((sc.n_chains + 1u) & ~1u)) + threadIdx.x;
-  }
-
+  ConstArgs A = pinned(args);
+  odd = uniform(odd) != 0;
+  total = uniform(total);
+  const RenderLds<LDS_SCENE> lds(smem, A);
+  const SceneTables tb = lds.tables(A);
+  typename RenderLds<LDS_SCENE>::Slot* const stack = lds.stack;
   const uint32_t region = blockIdx.x;
-  IterCounters* c = counters + parity;
-  IterCounters* nx = counters + (parity ^ 1);
-  const uint64_t issued = c->issued;
-  if (threadIdx.x < 64) {
-    // New paths are numbered through the free slots of region 0, then region 1, ...: every block works
-    // out where its own region's share starts.  Lane l looks after regions 4l .. 4l+3.
-    const uint32_t r4 = threadIdx.x * 4;
-    const uint32_t f0 = rc.region_cap - c->region[r4].n_cur, f1 = rc.region_cap - c->region[r4 + 1].n_cur;
-    const uint32_t f2 = rc.region_cap - c->region[r4 + 2].n_cur, f3 = rc.region_cap - c->region[r4 + 3].n_cur;
-    uint32_t total_free;
-    const uint32_t before = wave_exclusive_scan(f0 + f1 + f2 + f3, total_free);
-    const uint64_t remaining = rc.total_paths - issued;
-    const uint32_t n_new = remaining < (uint64_t)total_free ? (uint32_t)remaining : total_free;
-    if (threadIdx.x == region / 4) {
-      const uint32_t sub = region & 3u;
-      const uint32_t mine = sub == 0 ? f0 : (sub == 1 ? f1 : (sub == 2 ? f2 : f3));
-      const uint32_t first = before + (sub > 0 ? f0 : 0u) + (sub > 1 ? f1 : 0u) + (sub > 2 ? f2 : 0u);
-      sh.n_surv = rc.region_cap - mine;
-      sh.first_new = first;
-      sh.n_fresh = n_new > first ? min(n_new - first, mine) : 0u;
-      sh.next_work = 0;
-      sh.queue_n[0] = 0; sh.queue_n[1] = 0; sh.queue_n[2] = 0; sh.queue_n[3] = 0;
+  const uint32_t lane = lane_id();
+  const uint32_t cap = A->rc.region_cap;
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
+  uint32_t* const region_queues = A->queues + (size_t)region * N_QUEUES * cap;  // queue q at [q * cap, (q + 1) * cap)
+  const uint32_t root = RC::encode(A->sc.root_ref);
+  const uint32_t refill_min = A->refill_min, node_min = A->node_min;
+  Work work{};
+  uint32_t segments = 0;
+  long long ts = 0;
+  Walk w;
+  w.cur = RC::NONE;
+  uint32_t slot = NO_SLOT;  // slot of the ray this lane is walking
+  bool more = true;         // rays left to hand out, as far as this wave knows
+  // Every turn of this loop the wave first hands in finished rays and fetches new ones if enough lanes
+  // are without work, then steps down the tree until (almost) every lane holds a leaf, then tests one
+  // primitive in every lane that holds a leaf.
+  for (;;) {
+    const bool done = slot != NO_SLOT && w.cur == RC::NONE;
+    const unsigned long long m_done = __ballot(done);
+    const unsigned long long m_out = m_done | __ballot(slot == NO_SLOT);
+    const uint32_t n_out = (uint32_t)__popcll(m_out);
+    if (n_out == 64u && m_done == 0ull && !more) break;
+    if ((m_done != 0ull || more) && (n_out >= refill_min || n_out == 64u)) {
+      if (COUNT) ts = clock64();
+      // Rays that are done leave their hit in the record and their slot in the queue of the material
+      // hit.  Lane q reserves queue q's entries for the whole wave in the block's LDS counters; lane 4
+      // takes the wave's new rays off the region's list.
+      const int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(w.best_material));
+      const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
+      uint32_t got = 0;
+      if (lane < 4) {
+        const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+        const uint32_t cnt = (uint32_t)__popcll(mine);
+        if (cnt) got = atomicAdd(&sh.queue_n[lane], cnt);
+      } else if (lane == 4 && more) {
+        got = atomicAdd(&sh.next_work, n_out);
+      }
+      const uint32_t b0 = __builtin_amdgcn_readlane(got, 0), b1 = __builtin_amdgcn_readlane(got, 1);
+      const uint32_t b2 = __builtin_amdgcn_readlane(got, 2), b3 = __builtin_amdgcn_readlane(got, 3);
+      const uint32_t base = __builtin_amdgcn_readlane(got, 4);
+      if (done) {
+        const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
+        const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
+        const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+        region_queues[(size_t)q * cap + pos] = slot;
+        cur[4 * (size_t)slot + 3] =
+            make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), 0.0f);
+        slot = NO_SLOT;
+        ++segments;
+      }
+      if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_WRITE] += now - ts; ts = now; }
+      if (more) {
+        more = base + n_out < total;
+        const uint32_t entry = base + (uint32_t)__popcll(m_out & ((1ull << lane) - 1ull));
+        if (slot == NO_SLOT && entry < total) {
+          slot = entry;
+          const float4 r0 = cur[4 * (size_t)slot], r1 = cur[4 * (size_t)slot + 1];
+          Ray r;
+          r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
+          walk_begin(w, r, root);
+        }
+      }
+      if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
     }
-    if (region == 0) {  // shade counts the survivors of this iteration into the other parity's counters
-      nx->region[r4].n_cur = 0; nx->region[r4 + 1].n_cur = 0; nx->region[r4 + 2].n_cur = 0; nx->region[r4 + 3].n_cur = 0;
-      if (threadIdx.x == 0) nx->issued = issued + n_new;
+    if (COUNT) ts = clock64();
+    while (!(w.cur & RC::LEAF)) {
+      if (COUNT) { ++work.nodes; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_nodes; }
+      node_step<LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+      // the last few lanes still on their way down do not keep the others waiting
+      if ((uint32_t)__popcll(__ballot(!(w.cur & RC::LEAF))) < node_min) break;
+    }
+    if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_NODES] += now - ts; ts = now; }
+    if ((w.cur & RC::LEAF) && w.cur != RC::NONE) {
+      if (COUNT) { ++work.prims; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_prims; }
+      prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+    }
+    if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - ts;
+  }
+  if (COUNT) {
+    work_out->nodes += work.nodes; work_out->prims += work.prims;
+    work_out->wave_nodes += work.wave_nodes; work_out->wave_prims += work.wave_prims;
+    for (int k = 0; k < MIRT_PHASE_COUNT; ++k) work_out->cycles[k] += work.cycles[k];
+    *segments_out += segments;
+  }
+}
+
+// Shades the region's four queues (renderer.rs:141-212): constant media get their chance, the material
+// scatters or ends the path, survivors are packed into the first slots of the region's other buffer.
+template <bool COUNT, bool LDS_SCENE>
+__device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
+  constexpr int THREADS = RENDER_THREADS;
+  extern __shared__ float4 smem[];
+  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
+  ConstArgs A = pinned(args);
+  odd = uniform(odd) != 0;
+  const RenderLds<LDS_SCENE> lds(smem, A);
+  const SceneTables tb = lds.tables(A);
+  const uint32_t region = blockIdx.x;
+  const uint32_t lane = lane_id();
+  const uint32_t wave = uniform(threadIdx.x >> 6);
+  const ShadeTables sc = MIRT_SHADE_TABLES(A->sc);
+  const SceneTables gt = MIRT_GLOBAL_TABLES(A->sc);
+  const uint32_t n_media = A->sc.n_media;
+  struct { uint32_t width, height, max_depth, key0, key1; float background[3]; }
+      rc{A->rc.width, A->rc.height, A->rc.max_depth, A->rc.key0, A->rc.key1,
+         {A->rc.background[0], A->rc.background[1], A->rc.background[2]}};
+  const uint32_t cap = A->rc.region_cap;
+  const float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
+  float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
+  const uint32_t* const region_queues = A->queues + (size_t)region * N_QUEUES * cap;
+  float* const rgb_sum = A->rgb_sum;
+  for (uint32_t q = 0; q < N_QUEUES; ++q) {
+    const uint32_t n_q = sh.queue_n[q];
+    const uint32_t* entries = region_queues + (size_t)q * cap;
+    for (uint32_t e0 = wave * 64u; e0 < n_q; e0 += THREADS) {  // a wave shades 64 entries of one queue
+      const uint32_t e = e0 + lane;
+      bool alive = false;
+      Ray nr;
+      V3 beta = v3(0.0f, 0.0f, 0.0f);
+      uint32_t pixel = 0, sample = 0, bounce = 0;
+      if (e < n_q) {
+        const size_t i = entries[e];
+        const float4 r0 = cur[4 * i], r1 = cur[4 * i + 1], r2 = cur[4 * i + 2], r3 = cur[4 * i + 3];
+        Ray r;
+        r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
+        pixel = __float_as_uint(r1.w);
+        beta = xyz(r2);
+        sample = __float_as_uint(r2.w) >> 8;
+        bounce = __float_as_uint(r2.w) & 255u;
+        float t = r3.x;
+        uint32_t ref = __float_as_uint(r3.y);
+        if (n_media != 0) {  // the walk found the closest surface; the media in front of it get their chance now
+          uint32_t material = 0;
+          Rng mrng = rng_begin(pixel, sample, bounce, STAGE_MEDIA, rc.key0, rc.key1);
+          closest_media(n_media, tb, gt, sh.media, r, kTMin, mrng, ref, t, material);
+        }
+
+        V3 term = v3(0.0f, 0.0f, 0.0f);  // radiance that ends the path
+        if (ref == REF_NONE) {
+          term = v3(rc.background[0], rc.background[1], rc.background[2]);  // renderer.rs:187-189
+        } else {
+          const Hit h = hit_record<PSTRIDE>(tb, sh.media, ref, r, t, __float_as_uint(r3.z));
+          const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
+          Rng rng = rng_begin(pixel, sample, bounce, STAGE_SHADE, rc.key0, rc.key1);
+          if (m.kind == MIRT_MAT_LAMBERTIAN) {  // material.rs:39-58, renderer.rs:166-183
+            const V3 att = texture_color(sc, m.texture, h);
+            const Onb uvw = onb_from_w(h.n);
+            V3 dir;
+            float pdf;
+            if (sc.lights_mode != MIRT_LIGHTS_NONE) {
+              if (rng_next(rng) < 0.5f) dir = lights_random(sc, h.p, rng);  // pdf.rs:85-91
+              else dir = onb_local(uvw, random_cosine_direction(rng));
+              const float c1 = dot(unit(dir), uvw.w);  // pdf.rs:25-32
+              const float cos_pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
+              pdf = 0.5f * lights_pdf_value(sc, h.p, dir) + 0.5f * cos_pdf;  // pdf.rs:81-83
+            } else {
+              dir = onb_local(uvw, random_cosine_direction(rng));
+              const float c1 = dot(unit(dir), uvw.w);
+              pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
+            }
+            const float c2 = dot(h.n, unit(dir));  // material.rs:50-57
+            const float spdf = c2 < 0.0f ? 0.0f : c2 / kPi;
+            beta = ((beta * att) * spdf) / pdf;
+            nr.o = h.p; nr.d = dir; nr.time = r.time;
+            alive = true;
+          } else if (m.kind == MIRT_MAT_METAL) {  // material.rs:75-91
+            const V3 reflected = reflect(unit(r.d), h.n);
+            const V3 fuzz = m.param * random_in_unit_sphere(rng);
+            const V3 att = texture_color(sc, m.texture, h);
+            beta = beta * att;
+            nr.o = h.p; nr.d = reflected + fuzz; nr.time = r.time;
+            alive = true;
+          } else if (m.kind == MIRT_MAT_DIELECTRIC) {  // material.rs:111-137
+            const float ratio = h.front ? 1.0f / m.param : m.param;
+            const V3 ud = unit(r.d);
+            const float cos_theta = fminf(dot(-ud, h.n), 1.0f);
+            const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            bool do_reflect = ratio * sin_theta > 1.0f;
+            if (!do_reflect) do_reflect = reflectance(cos_theta, ratio) > rng_next(rng);
+            nr.d = do_reflect ? reflect(ud, h.n) : refract(ud, h.n, ratio);
+            nr.o = h.p; nr.time = r.time;
+            alive = true;
+          } else if (m.kind == MIRT_MAT_DIFFUSE_LIGHT) {  // material.rs:151-158
+            if (h.front) term = texture_color(sc, m.texture, h);
+          }
+          // MIRT_MAT_ISOTROPIC: no scatter, no emission
+        }
+        // The child call at depth 0 returns black without tracing (renderer.rs:147-149).
+        if (alive && bounce + 1 >= rc.max_depth) alive = false;
+        if (!alive) {
+          // beta * term is the path's whole contribution; it is added even when
+          // term is zero if beta is NaN/inf so a poisoned sample blackens its
+          // pixel as in the reference (renderer.rs:241-252: NaN as u8 == 0)
+          const V3 cval = beta * term;
+          if (!(cval.x == 0.0f && cval.y == 0.0f && cval.z == 0.0f)) {
+            const uint32_t y = pixel / rc.width, x = pixel - y * rc.width;
+            float* dst = rgb_sum + ((size_t)(rc.height - 1 - y) * rc.width + x) * 3;
+            atomicAdd(dst, cval.x);
+            atomicAdd(dst + 1, cval.y);
+            atomicAdd(dst + 2, cval.z);
+          }
+        }
+      }
+      // survivors are packed into the first slots of the region's other buffer
+      const size_t to = wave_reserve(alive, &sh.n_next);
+      if (alive) {
+        next[4 * to] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
+        next[4 * to + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
+        next[4 * to + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
+      }
     }
   }
-  __syncthreads();
+}
+
+// The whole render in one launch.  Block s owns region s of the path pool and stays resident until the
+// render is done: it stages the scene in LDS once, then goes round
+//   start   camera paths in the region's free slots, taking their numbers from a counter all blocks share,
+//   walk    every live ray to its closest surface and into the region's queue for the material hit,
+//   shade   queue by queue; survivors go to the first slots of the region's other buffer,
+// until the region has no live path and the counter has run out.  No block waits for another one.
+//
+// LDS_SCENE: nodes, primitive records and wrapper chains are staged in LDS, so neither walk nor shade waits
+// on global memory for the scene; otherwise those tables are read from global memory.
+template <bool COUNT, bool LDS_SCENE>
+__global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __restrict__ args) {
+  constexpr int THREADS = RENDER_THREADS;
+  extern __shared__ float4 smem[];
+  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  {
+    ConstArgs A = pinned(args);
+    stage_media(A->sc.n_media, A->sc.media, A->sc.prims, sh.media);
+    if (LDS_SCENE) {
+      const RenderLds<true> lds(smem, A);
+      const float4 *nodes = A->sc.nodes, *prims = A->sc.prims, *chain_ops = A->sc.chain_ops;
+      const uint2* chains = A->sc.chains;
+      const uint32_t n_node_quads = A->sc.n_nodes * 4u, n_prim_quads = A->sc.n_prims * PRIM_QUADS_LDS;
+      const uint32_t n_chain_ops = A->sc.n_chain_ops, n_chains = A->sc.n_chains;
+      for (uint32_t k = threadIdx.x; k < n_node_quads; k += THREADS) {
+        float4 q = nodes[k];
+        if ((k & 3u) < 2u) q.w = __uint_as_float(RefCode<true>::encode(__float_as_uint(q.w)));  // child refs
+        lds.nodes[k] = q;
+      }
+      for (uint32_t k = threadIdx.x; k < n_prim_quads; k += THREADS)
+        lds.prims[k] = prims[(k / PRIM_QUADS_LDS) * PRIM_QUADS + (k % PRIM_QUADS_LDS)];
+      for (uint32_t k = threadIdx.x; k < n_chain_ops; k += THREADS) lds.ops[k] = chain_ops[k];
+      for (uint32_t k = threadIdx.x; k < n_chains; k += THREADS) lds.chains[k] = chains[k];
+    }
+  }
 
   Work work{};
   long long k_begin = 0, ts = 0;
   if (COUNT) k_begin = clock64();
-  uint32_t segments = 0;
-  const uint32_t lane = lane_id();
-  const uint32_t n_surv = sh.n_surv, n_fresh = sh.n_fresh, first_new = sh.first_new;
-  const size_t slot0 = (size_t)region * rc.region_cap;
-
-  // ---- new camera paths (renderer.rs:215-218, camera.rs:57-68) ----------------------------------------
-  if (COUNT) ts = clock64();
-  {
-    const uint32_t pixels = rc.width * rc.height;
-    for (uint32_t k = threadIdx.x; k < n_fresh; k += THREADS) {
-      const size_t i = slot0 + n_surv + k;
-      const uint64_t g = issued + first_new + k;
-      const uint32_t pass = (uint32_t)(g / pixels);
-      uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
-      // Consecutive groups of 64 paths start far apart in the image, so that every region's new paths are a
-      // sample of the whole frame and the regions cost about the same to trace.
-      const uint32_t group = in_pass >> 6;
-      if (group < rc.n_groups) in_pass = (((group * rc.group_stride) % rc.n_groups) << 6) | (in_pass & 63u);
-      uint32_t x, y;
-      pixel_of(in_pass, rc.width, rc.height, x, y);
-      const uint32_t pixel = y * rc.width + x;
-      const uint32_t sample = rc.first_sample + pass;
-      Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, rc.key0, rc.key1);
-      const float u = ((float)x + rng_next(rng)) / (float)(rc.width - 1);
-      const float v = ((float)y + rng_next(rng)) / (float)(rc.height - 1);
-      V3 disk;
-      for (;;) {  // vec3.rs:53-60
-        const float dx = rng_range(rng, -1.0f, 1.0f);
-        const float dy = rng_range(rng, -1.0f, 1.0f);
-        disk = v3(dx, dy, 0.0f);
-        if (len2(disk) < 1.0f) break;
+  uint32_t segments = 0, rounds = 0;
+  uint32_t n_surv = 0;      // the region carries survivors in its slots [0, n_surv)
+  bool exhausted = false;   // the shared counter has handed out the render's last path (thread 0 only)
+  for (;;) {
+    if (threadIdx.x == 0) {
+      ConstArgs A = pinned(args);
+      uint32_t fresh = 0;
+      const uint32_t n_free = A->rc.region_cap - n_surv;
+      const unsigned long long total_paths = A->rc.total_paths;
+      if (n_free != 0 && !exhausted) {
+        const unsigned long long first = atomicAdd(&A->state->issued, (unsigned long long)n_free);
+        if (first < total_paths) {
+          const unsigned long long left = total_paths - first;
+          fresh = left < n_free ? (uint32_t)left : n_free;
+        }
+        exhausted = first + n_free >= total_paths;
+        sh.first_new_lo = (uint32_t)first;
+        sh.first_new_hi = (uint32_t)(first >> 32);
       }
-      const mirt_camera& cam = rc.cam;
-      const V3 rd = rc.cam.lens_radius * disk;
-      const V3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]);
-      const V3 offset = cu * rd.x + cv * rd.y;
-      const V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
-      const V3 llc = v3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
-      const V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
-      const V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
-      const V3 d = llc + u * hor + v * ver - origin - offset;
-      const V3 o = origin + offset;
-      const float time = rng_range(rng, cam.time0, cam.time1);
-      cur[4 * i] = make_float4(o.x, o.y, o.z, time);
-      cur[4 * i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
-      cur[4 * i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
+      sh.n_fresh = fresh;
+      sh.next_work = 0;
+      sh.queue_n[0] = 0; sh.queue_n[1] = 0; sh.queue_n[2] = 0; sh.queue_n[3] = 0;
+      sh.n_next = 0;
     }
-  }
-  if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
-  __syncthreads();  // the new rays are visible to the whole block
-
-  // ---- closest surfaces ---------------------------------------------------------------------------
-  {
-    const uint32_t root = RC::encode(sc.root_ref);
+    __syncthreads();  // also: the staged scene is complete before the first walk
+    const uint32_t n_fresh = sh.n_fresh;
     const uint32_t total = n_surv + n_fresh;
-    uint32_t* const region_queues = queues + (size_t)region * rc.region_cap;
-    const size_t queue_stride = (size_t)N_REGIONS * rc.region_cap;
-    Walk w;
-    w.cur = RC::NONE;
-    uint32_t slot = NO_SLOT;  // local slot of the ray this lane is walking
-    bool more = total != 0;   // rays left to hand out, as far as this wave knows
-    // Every turn of this loop the wave first hands in finished rays and fetches new ones if enough lanes
-    // are without work, then steps down the tree until (almost) every lane holds a leaf, then tests one
-    // primitive in every lane that holds a leaf.
-    for (;;) {
-      const bool done = slot != NO_SLOT && w.cur == RC::NONE;
-      const unsigned long long m_done = __ballot(done);
-      const unsigned long long m_out = m_done | __ballot(slot == NO_SLOT);
-      const uint32_t n_out = (uint32_t)__popcll(m_out);
-      if (n_out == 64u && m_done == 0ull && !more) break;
-      if ((m_done != 0ull || more) && (n_out >= refill_min || n_out == 64u)) {
-        if (COUNT) ts = clock64();
-        // Rays that are done leave their hit in the record and their slot in the queue of the material hit.
-        // Lane q reserves queue q's entries for the whole wave in the block's LDS counters; lane 4 takes
-        // the wave's new rays off the region's list.
-        const int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(w.best_material));
-        const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
-        uint32_t got = 0;
-        if (lane < 4) {
-          const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
-          const uint32_t cnt = (uint32_t)__popcll(mine);
-          if (cnt) got = atomicAdd(&sh.queue_n[lane], cnt);
-        } else if (lane == 4 && more) {
-          got = atomicAdd(&sh.next_work, n_out);
-        }
-        const uint32_t b0 = __builtin_amdgcn_readlane(got, 0), b1 = __builtin_amdgcn_readlane(got, 1);
-        const uint32_t b2 = __builtin_amdgcn_readlane(got, 2), b3 = __builtin_amdgcn_readlane(got, 3);
-        const uint32_t base = __builtin_amdgcn_readlane(got, 4);
-        if (done) {
-          const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
-          const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
-          const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
-          region_queues[(size_t)q * queue_stride + pos] = (uint32_t)(slot0 + slot);
-          cur[4 * (slot0 + slot) + 3] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), 0.0f);
-          slot = NO_SLOT;
-          ++segments;
-        }
-        if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_WRITE] += now - ts; ts = now; }
-        if (more) {
-          more = base + n_out < total;
-          const uint32_t entry = base + (uint32_t)__popcll(m_out & ((1ull << lane) - 1ull));
-          if (slot == NO_SLOT && entry < total) {
-            slot = entry;
-            const float4 r0 = cur[4 * (slot0 + slot)], r1 = cur[4 * (slot0 + slot) + 1];
-            Ray r;
-            r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
-            walk_begin(w, r, root);
-          }
-        }
-        if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
-      }
-      if (COUNT) ts = clock64();
-      while (!(w.cur & RC::LEAF)) {
-        if (COUNT) { ++work.nodes; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_nodes; }
-        node_step<LDS_SCENE>(w, tb, kTMin, stack, THREADS);
-        // the last few lanes still on their way down do not keep the others waiting
-        if ((uint32_t)__popcll(__ballot(!(w.cur & RC::LEAF))) < node_min) break;
-      }
-      if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_NODES] += now - ts; ts = now; }
-      if ((w.cur & RC::LEAF) && w.cur != RC::NONE) {
-        if (COUNT) { ++work.prims; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_prims; }
-        prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, stack, THREADS);
-      }
-      if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - ts;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < N_QUEUES) c->region[region].queue_n[threadIdx.x] = sh.queue_n[threadIdx.x];
-  if (COUNT && threadIdx.x == 0) work_out->block_busy[region] += (unsigned long long)(wall_clock64() - block_begin);
+    if (total == 0) break;  // nothing alive and nothing left to start: the region is done
+    const bool odd = (rounds & 1u) != 0;  // the region's two buffers swap roles every round
+    ++rounds;
 
+    if (COUNT) ts = clock64();
+    start_paths<COUNT>(args, odd, n_surv, n_fresh, ((uint64_t)sh.first_new_hi << 32) | sh.first_new_lo);
+    if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
+    __syncthreads();  // the new rays are visible to the whole block
+    walk_rays<COUNT, LDS_SCENE>(args, odd, total, &work, &segments);
+    __syncthreads();  // every live slot carries its surface hit and sits in one of the four queues
+    if (COUNT) ts = clock64();
+    shade_queues<COUNT, LDS_SCENE>(args, odd);
+    if (COUNT) work.cycles[MIRT_PHASE_SHADE] += clock64() - ts;
+    __syncthreads();
+    n_surv = sh.n_next;
+    __syncthreads();  // everyone has read the counters thread 0 is about to reset
+  }
+
+  WorkCounters* const work_out = pinned(args)->work;
+  if (threadIdx.x == 0) atomicMax(&work_out->rounds, rounds);
   if (COUNT) {
     work.cycles[MIRT_PHASE_TOTAL] = clock64() - k_begin;
     // one atomic per wave; a lane's phase clocks stop when it leaves a loop early, so the wave's time is the max
@@ -1087,165 +1311,13 @@ __global__ __launch_bounds__(EXTEND_THREADS) void k_extend(DeviceScene sc, Rende
         work.cycles[k] = other > work.cycles[k] ? other : work.cycles[k];
       }
     }
-    if (lane == 0) {
+    if (lane_id() == 0) {
       atomicAdd(&work_out->nodes, (unsigned long long)work.nodes);
       atomicAdd(&work_out->prims, (unsigned long long)work.prims);
       atomicAdd(&work_out->wave_nodes, (unsigned long long)work.wave_nodes);
       atomicAdd(&work_out->wave_prims, (unsigned long long)work.wave_prims);
       atomicAdd(&work_out->segments, (unsigned long long)segments);
       for (int k = 0; k < MIRT_PHASE_COUNT; ++k) atomicAdd(&work_out->cycles[k], (unsigned long long)work.cycles[k]);
-    }
-  }
-}
-
-// ---- shade ------------------------------------------------------------------------
-constexpr uint32_t N_SEGMENTS = N_QUEUES * N_REGIONS;  // one per (material queue, region), queue-major
-
-__global__ __launch_bounds__(BLOCK_THREADS) void k_shade(DeviceScene sc, RenderConst rc,
-                                                         const float4* __restrict__ cur, float4* __restrict__ next,
-                                                         IterCounters* counters, int parity,
-                                                         const uint32_t* __restrict__ queues,
-                                                         float* __restrict__ rgb_sum) {
-  // All segments laid end to end, each starting on a wave boundary: a wave shades one
-  // material of one region.  seg_start[k] = first virtual index of segment k.
-  __shared__ uint32_t seg_start[N_SEGMENTS + 1];
-  __shared__ uint32_t seg_count[N_SEGMENTS];
-  __shared__ MediumEntry media[MIRT_MAX_MEDIA];
-  stage_media(sc, media);
-  const SceneTables tb = global_tables(sc);
-  IterCounters* c = counters + parity;
-  IterCounters* nx = counters + (parity ^ 1);
-  if (threadIdx.x < 64) {  // each lane of the first wave owns N_SEGMENTS / 64 consecutive segments
-    constexpr uint32_t PER = N_SEGMENTS / 64;
-    uint32_t sum = 0;
-    for (uint32_t k = 0; k < PER; ++k) {
-      const uint32_t seg = threadIdx.x * PER + k;
-      const uint32_t cnt = c->region[seg % N_REGIONS].queue_n[seg / N_REGIONS];
-      seg_count[seg] = cnt;
-      sum += (cnt + 63u) & ~63u;
-    }
-    uint32_t total;
-    uint32_t start = wave_exclusive_scan(sum, total);
-    for (uint32_t k = 0; k < PER; ++k) {
-      const uint32_t seg = threadIdx.x * PER + k;
-      seg_start[seg] = start;
-      start += (seg_count[seg] + 63u) & ~63u;
-    }
-    if (threadIdx.x == 63) seg_start[N_SEGMENTS] = total;
-  }
-  __syncthreads();
-  const uint32_t total = seg_start[N_SEGMENTS];
-  const uint32_t stride = gridDim.x * BLOCK_THREADS;
-  const uint32_t rounds = (total + stride - 1) / stride;
-  for (uint32_t round = 0; round < rounds; ++round) {
-    const uint32_t j = round * stride + blockIdx.x * BLOCK_THREADS + threadIdx.x;
-    // segment of this wave: the last one starting at or before its first virtual index
-    const uint32_t j0 = j & ~63u;
-    uint32_t lo = 0, hi = N_SEGMENTS;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (seg_start[mid] <= j0) lo = mid; else hi = mid;
-    }
-    const uint32_t seg = lo;
-    const uint32_t q = seg / N_REGIONS, region = seg % N_REGIONS;
-    const uint32_t k = j - seg_start[seg];
-    const bool active = j < total && k < seg_count[seg];
-
-    bool alive = false;
-    Ray nr;
-    V3 beta = v3(0.0f, 0.0f, 0.0f);
-    uint32_t pixel = 0, sample = 0, bounce = 0;
-    if (active) {
-      const uint32_t i = queues[((size_t)q * N_REGIONS + region) * rc.region_cap + k];
-      const float4 r0 = cur[4 * (size_t)i], r1 = cur[4 * (size_t)i + 1];
-      const float4 r2 = cur[4 * (size_t)i + 2], r3 = cur[4 * (size_t)i + 3];
-      Ray r;
-      r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
-      pixel = __float_as_uint(r1.w);
-      beta = xyz(r2);
-      sample = __float_as_uint(r2.w) >> 8;
-      bounce = __float_as_uint(r2.w) & 255u;
-      float t = r3.x;
-      uint32_t ref = __float_as_uint(r3.y);
-      if (sc.n_media != 0) {  // extend found the closest surface; the media in front of it get their chance now
-        uint32_t material = 0;
-        Rng mrng = rng_begin(pixel, sample, bounce, STAGE_MEDIA, rc.key0, rc.key1);
-        closest_media(sc, tb, media, r, kTMin, mrng, ref, t, material);
-      }
-
-      V3 term = v3(0.0f, 0.0f, 0.0f);  // radiance that ends the path
-      if (ref == REF_NONE) {
-        term = v3(rc.background[0], rc.background[1], rc.background[2]);  // renderer.rs:187-189
-      } else {
-        const Hit h = hit_record(sc, ref, r, t, __float_as_uint(r3.z));
-        const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
-        Rng rng = rng_begin(pixel, sample, bounce, STAGE_SHADE, rc.key0, rc.key1);
-        if (m.kind == MIRT_MAT_LAMBERTIAN) {  // material.rs:39-58, renderer.rs:166-183
-          const V3 att = texture_color(sc, m.texture, h);
-          const Onb uvw = onb_from_w(h.n);
-          V3 dir;
-          float pdf;
-          if (sc.lights_mode != MIRT_LIGHTS_NONE) {
-            if (rng_next(rng) < 0.5f) dir = lights_random(sc, h.p, rng);  // pdf.rs:85-91
-            else dir = onb_local(uvw, random_cosine_direction(rng));
-            const float c1 = dot(unit(dir), uvw.w);  // pdf.rs:25-32
-            const float cos_pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
-            pdf = 0.5f * lights_pdf_value(sc, h.p, dir) + 0.5f * cos_pdf;  // pdf.rs:81-83
-          } else {
-            dir = onb_local(uvw, random_cosine_direction(rng));
-            const float c1 = dot(unit(dir), uvw.w);
-            pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
-          }
-          const float c2 = dot(h.n, unit(dir));  // material.rs:50-57
-          const float spdf = c2 < 0.0f ? 0.0f : c2 / kPi;
-          beta = ((beta * att) * spdf) / pdf;
-          nr.o = h.p; nr.d = dir; nr.time = r.time;
-          alive = true;
-        } else if (m.kind == MIRT_MAT_METAL) {  // material.rs:75-91
-          const V3 reflected = reflect(unit(r.d), h.n);
-          const V3 fuzz = m.param * random_in_unit_sphere(rng);
-          const V3 att = texture_color(sc, m.texture, h);
-          beta = beta * att;
-          nr.o = h.p; nr.d = reflected + fuzz; nr.time = r.time;
-          alive = true;
-        } else if (m.kind == MIRT_MAT_DIELECTRIC) {  // material.rs:111-137
-          const float ratio = h.front ? 1.0f / m.param : m.param;
-          const V3 ud = unit(r.d);
-          const float cos_theta = fminf(dot(-ud, h.n), 1.0f);
-          const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-          bool do_reflect = ratio * sin_theta > 1.0f;
-          if (!do_reflect) do_reflect = reflectance(cos_theta, ratio) > rng_next(rng);
-          nr.d = do_reflect ? reflect(ud, h.n) : refract(ud, h.n, ratio);
-          nr.o = h.p; nr.time = r.time;
-          alive = true;
-        } else if (m.kind == MIRT_MAT_DIFFUSE_LIGHT) {  // material.rs:151-158
-          if (h.front) term = texture_color(sc, m.texture, h);
-        }
-        // MIRT_MAT_ISOTROPIC: no scatter, no emission
-      }
-      // The child call at depth 0 returns black without tracing (renderer.rs:147-149).
-      if (alive && bounce + 1 >= rc.max_depth) alive = false;
-      if (!alive) {
-        // beta * term is the path's whole contribution; it is added even when
-        // term is zero if beta is NaN/inf so a poisoned sample blackens its
-        // pixel as in the reference (renderer.rs:241-252: NaN as u8 == 0)
-        const V3 cval = beta * term;
-        if (!(cval.x == 0.0f && cval.y == 0.0f && cval.z == 0.0f)) {
-          const uint32_t y = pixel / rc.width, x = pixel - y * rc.width;
-          float* dst = rgb_sum + ((size_t)(rc.height - 1 - y) * rc.width + x) * 3;
-          atomicAdd(dst, cval.x);
-          atomicAdd(dst + 1, cval.y);
-          atomicAdd(dst + 2, cval.z);
-        }
-      }
-    }
-    // survivors are compacted into the same region of the other buffer (one atomic per wave)
-    const uint32_t local = wave_reserve(alive, &nx->region[region].n_cur);
-    if (alive) {
-      const size_t slot = (size_t)region * rc.region_cap + local;
-      next[4 * slot] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
-      next[4 * slot + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
-      next[4 * slot + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
     }
   }
 }
@@ -1273,7 +1345,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
   __shared__ uint32_t stack_mem[STACK_DEPTH * BLOCK_THREADS];
   __shared__ MediumEntry media[MIRT_MAX_MEDIA];
   uint32_t* stack = stack_mem + threadIdx.x;
-  stage_media(sc, media);
+  stage_media(sc.n_media, sc.media, sc.prims, media);
   __syncthreads();
   const size_t i = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
   if (i >= n) return;
@@ -1285,12 +1357,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
   uint32_t ref, material, face;
   float t;
   Work work{};
-  const SceneTables tb = global_tables(sc);
+  const SceneTables tb = MIRT_GLOBAL_TABLES(sc);
   closest_surface<false, (int)PRIM_QUADS, false>(tb, sc.root_ref, r, kTMin, stack, BLOCK_THREADS, ref, t, material, face,
                                                  work);
   if (sc.n_media != 0) {
     Rng rng = rng_begin((uint32_t)i, 0, 0, STAGE_MEDIA, key0, key1);
-    closest_media(sc, tb, media, r, kTMin, rng, ref, t, material);
+    closest_media(sc.n_media, tb, tb, media, r, kTMin, rng, ref, t, material);
   }
   uint32_t ti = 0xFFFFFFFFu, oi = 0xFFFFFFFFu;
   if (ref != REF_NONE) {
@@ -1298,7 +1370,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
       ti = sc.media[ref_index(ref)].type_index;
       oi = sc.media[ref_index(ref)].object_index;
     } else {
-      const uint2 id = prim_ids(sc, ref);
+      const uint2 id = sc.prim_ids[ref_index(ref)];
       ti = id.x; oi = id.y;
     }
   }
@@ -1310,32 +1382,32 @@ __global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const m
 }  // namespace
 
 // ---- launchers ------------------------------------------------------------------------
-ExtendConfig plan_extend(const DeviceScene& sc) {
-  ExtendConfig cfg{};
-  cfg.block = EXTEND_THREADS;
+RenderConfig plan_render(const DeviceScene& sc) {
+  RenderConfig cfg{};
+  cfg.block = RENDER_THREADS;
   cfg.grid = N_REGIONS;
   // a stack entry per inner node on the path plus the pending sibling of the last one
   const int depth = (int)sc.bvh_height + 2;
   const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * PRIM_QUADS_LDS * 16 +
                              (size_t)sc.n_chain_ops * 16 + (size_t)((sc.n_chains + 1u) & ~1u) * 8;
   // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes
-  const size_t lds_total = sizeof(ExtendShared) + scene_bytes + (size_t)depth * EXTEND_THREADS * 2;
+  const size_t lds_total = sizeof(RenderShared) + scene_bytes + (size_t)depth * RENDER_THREADS * 2;
   if (lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
-    cfg.lds_nodes = true;
+    cfg.lds_scene = true;
     cfg.stack_depth = depth;
     cfg.lds_bytes = lds_total;
   } else {
-    cfg.lds_nodes = false;
+    cfg.lds_scene = false;
     cfg.stack_depth = STACK_DEPTH;
-    cfg.lds_bytes = sizeof(ExtendShared) + (size_t)STACK_DEPTH * EXTEND_THREADS * 4;
+    cfg.lds_bytes = sizeof(RenderShared) + (size_t)STACK_DEPTH * RENDER_THREADS * 4;
   }
   cfg.refill_min = 16;
   cfg.node_min = 16;
-  if (const char* e = std::getenv("MIRT_EXTEND_REFILL")) {  // tuning aids
+  if (const char* e = std::getenv("MIRT_REFILL_MIN")) {  // tuning aids
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 1 && v <= 64) cfg.refill_min = (uint32_t)v;
   }
-  if (const char* e = std::getenv("MIRT_EXTEND_NODE_MIN")) {
+  if (const char* e = std::getenv("MIRT_NODE_MIN")) {
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 1 && v <= 64) cfg.node_min = (uint32_t)v;
   }
@@ -1343,37 +1415,23 @@ ExtendConfig plan_extend(const DeviceScene& sc) {
 }
 
 template <bool COUNT, bool LDS_SCENE>
-static hipError_t launch_extend_as(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters,
-                                   int parity, WorkCounters* work, uint32_t* queues, const ExtendConfig& cfg,
-                                   hipStream_t stream) {
+static hipError_t launch_render_as(const RenderArgs* args, const RenderConfig& cfg, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<COUNT, LDS_SCENE>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<COUNT, LDS_SCENE>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_extend<COUNT, LDS_SCENE>), dim3(cfg.grid), dim3(EXTEND_THREADS), cfg.lds_bytes, stream, sc, rc,
-                     cur, counters, parity, work, queues, cfg.refill_min, cfg.node_min);
+  hipLaunchKernelGGL((k_render<COUNT, LDS_SCENE>), dim3(cfg.grid), dim3(RENDER_THREADS), cfg.lds_bytes, stream, args);
   return hipGetLastError();
 }
 
-hipError_t launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters, int parity,
-                         WorkCounters* work, uint32_t* queues, bool count_work, const ExtendConfig& cfg,
-                         hipStream_t stream) {
-  if (cfg.lds_nodes) {
-    return count_work ? launch_extend_as<true, true>(sc, rc, cur, counters, parity, work, queues, cfg, stream)
-                      : launch_extend_as<false, true>(sc, rc, cur, counters, parity, work, queues, cfg, stream);
+hipError_t launch_render(const RenderArgs* args, bool count_work, const RenderConfig& cfg, hipStream_t stream) {
+  if (cfg.lds_scene) {
+    return count_work ? launch_render_as<true, true>(args, cfg, stream) : launch_render_as<false, true>(args, cfg, stream);
   }
-  return count_work ? launch_extend_as<true, false>(sc, rc, cur, counters, parity, work, queues, cfg, stream)
-                    : launch_extend_as<false, false>(sc, rc, cur, counters, parity, work, queues, cfg, stream);
-}
-
-void launch_shade(const DeviceScene& sc, const RenderConst& rc, const float4* cur, float4* next,
-                  IterCounters* counters, int parity, const uint32_t* queues, float* rgb_sum, int grid,
-                  hipStream_t stream) {
-  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(BLOCK_THREADS), 0, stream, sc, rc, cur, next, counters, parity, queues,
-                     rgb_sum);
+  return count_work ? launch_render_as<true, false>(args, cfg, stream) : launch_render_as<false, false>(args, cfg, stream);
 }
 
 void launch_resolve(const float* rgb_sum, uint32_t n_values, uint32_t spp, uint8_t* rgb24, hipStream_t stream) {
@@ -1388,12 +1446,6 @@ void launch_trace(const DeviceScene& sc, const mirt_ray* rays, size_t n, uint32_
   const size_t grid = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
   hipLaunchKernelGGL(k_trace, dim3((uint32_t)grid), dim3(BLOCK_THREADS), 0, stream, sc, rays, n, key0, key1,
                      type_index, object_index, t);
-}
-
-int shade_blocks_per_cu() {
-  int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, BLOCK_THREADS, 0) != hipSuccess || n < 1) n = 4;
-  return n > 8 ? 8 : n;
 }
 
 }  // namespace mirt

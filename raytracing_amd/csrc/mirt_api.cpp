@@ -59,11 +59,11 @@ struct mirt_context {
   // render workspace, grown on demand and kept between calls
   DeviceBuffer paths[2];
   DeviceBuffer queues;
-  DeviceBuffer counters;
+  DeviceBuffer state;
+  DeviceBuffer args;
   DeviceBuffer work;
   DeviceBuffer image_sum;
   DeviceBuffer image_rgb;
-  int shade_blocks = 0;
 };
 
 struct mirt_scene {
@@ -249,7 +249,6 @@ int mirt_context_create(int device_id, mirt_context** out) {
     delete ctx;
     return fail(nullptr, MIRT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   }
-  ctx->shade_blocks = shade_blocks_per_cu();
   *out = ctx;
   return MIRT_OK;
 }
@@ -520,9 +519,9 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   MIRT_HIP(ctx, ctx->paths[0].ensure((size_t)pool * 64));
   MIRT_HIP(ctx, ctx->paths[1].ensure((size_t)pool * 64));
   MIRT_HIP(ctx, ctx->queues.ensure((size_t)pool * 4 * N_QUEUES));
-  MIRT_HIP(ctx, ctx->counters.ensure(2 * sizeof(IterCounters)));
+  MIRT_HIP(ctx, ctx->state.ensure(sizeof(RenderState)));
   MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
-  MIRT_HIP(ctx, hipMemsetAsync(ctx->counters.ptr, 0, 2 * sizeof(IterCounters), stream));
+  MIRT_HIP(ctx, hipMemsetAsync(ctx->state.ptr, 0, sizeof(RenderState), stream));
   MIRT_HIP(ctx, hipMemsetAsync(ctx->work.ptr, 0, sizeof(WorkCounters), stream));
 
   RenderConst rc{};
@@ -550,94 +549,61 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
 
   const bool count_work = (p.flags & MIRT_RENDER_COUNT_WORK) != 0;
   const bool time_kernels = (p.flags & MIRT_RENDER_TIME_KERNELS) != 0;
-  const ExtendConfig extend_cfg = plan_extend(scene->view);
+  const RenderConfig cfg = plan_render(scene->view);
   if (std::getenv("MIRT_VERBOSE"))
-    std::fprintf(stderr, "mirt: %zu prims, %u nodes, height %u; extend %s, %d x %d threads, %zu B LDS, stack %d; pool %u\n",
+    std::fprintf(stderr, "mirt: %zu prims, %u nodes, height %u; %s, %d x %d threads, %zu B LDS, stack %d; pool %u\n",
                  scene->n_prims, scene->view.n_nodes, scene->view.bvh_height,
-                 extend_cfg.lds_nodes ? "scene in LDS" : "scene in global memory", extend_cfg.grid, extend_cfg.block,
-                 extend_cfg.lds_bytes, extend_cfg.stack_depth, pool);
-  const int shade_grid = std::max(1, std::min(ctx->num_cu * ctx->shade_blocks, (int)((pool + 255u) / 256u)));
+                 cfg.lds_scene ? "scene in LDS" : "scene in global memory", cfg.grid, cfg.block, cfg.lds_bytes,
+                 cfg.stack_depth, pool);
 
-  std::vector<hipEvent_t> events;  // start/stop pairs: extend, shade, extend, shade, ...
+  hipEvent_t ev[2] = {nullptr, nullptr};
   struct EventGuard {
-    std::vector<hipEvent_t>& ev;
-    ~EventGuard() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
-  } event_guard{events};
-  auto stamp = [&]() -> hipError_t {
-    hipEvent_t e;
-    hipError_t r = hipEventCreate(&e);
-    if (r != hipSuccess) return r;
-    events.push_back(e);
-    return hipEventRecord(e, stream);
-  };
-
-  float4* cur = ctx->paths[0].as<float4>();
-  float4* next = ctx->paths[1].as<float4>();
-  IterCounters* counters = ctx->counters.as<IterCounters>();
-  uint32_t* queues = ctx->queues.as<uint32_t>();
-  int parity = 0;
-  uint32_t iterations = 0;
-  uint64_t issued_seen = 0;
-  const auto t_begin = std::chrono::steady_clock::now();
-  for (;;) {
-    const uint64_t remaining = total - issued_seen;
-    uint64_t burst = remaining ? (remaining + pool - 1) / pool : p.max_depth;
-    burst = std::max<uint64_t>(1, std::min<uint64_t>(burst, 256));
-    for (uint64_t b = 0; b < burst; ++b) {
-      if (time_kernels) MIRT_HIP(ctx, stamp());
-      MIRT_HIP(ctx, launch_extend(scene->view, rc, cur, counters, parity, ctx->work.as<WorkCounters>(), queues,
-                                  count_work, extend_cfg, stream));
-      if (time_kernels) { MIRT_HIP(ctx, stamp()); MIRT_HIP(ctx, stamp()); }
-      launch_shade(scene->view, rc, cur, next, counters, parity, queues, rgb_sum_device, shade_grid, stream);
-      if (time_kernels) MIRT_HIP(ctx, stamp());
-      std::swap(cur, next);
-      parity ^= 1;
-      ++iterations;
-    }
-    MIRT_HIP(ctx, hipGetLastError());
-    IterCounters h{};
-    MIRT_HIP(ctx, hipMemcpyAsync(&h, counters + parity, sizeof(h), hipMemcpyDeviceToHost, stream));
-    MIRT_HIP(ctx, hipStreamSynchronize(stream));
-    issued_seen = h.issued;
-    uint64_t alive = 0;
-    for (uint32_t r = 0; r < N_REGIONS; ++r) alive += h.region[r].n_cur;
-    if (issued_seen >= total && alive == 0) break;
-    if (iterations > 100000000u) return fail(ctx, MIRT_ERR_DEVICE, "render did not converge");
+    hipEvent_t* ev;
+    ~EventGuard() { for (int k = 0; k < 2; ++k) if (ev[k]) (void)hipEventDestroy(ev[k]); }
+  } event_guard{ev};
+  if (time_kernels) {
+    MIRT_HIP(ctx, hipEventCreate(&ev[0]));
+    MIRT_HIP(ctx, hipEventCreate(&ev[1]));
+    MIRT_HIP(ctx, hipEventRecord(ev[0], stream));
   }
+  const auto t_begin = std::chrono::steady_clock::now();
+  RenderArgs args{};
+  args.sc = scene->view;
+  args.rc = rc;
+  args.paths_a = ctx->paths[0].as<float4>();
+  args.paths_b = ctx->paths[1].as<float4>();
+  args.queues = ctx->queues.as<uint32_t>();
+  args.state = ctx->state.as<RenderState>();
+  args.work = ctx->work.as<WorkCounters>();
+  args.rgb_sum = rgb_sum_device;
+  args.refill_min = cfg.refill_min;
+  args.node_min = cfg.node_min;
+  MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
+  // (pageable source: the copy has left `args` by the time the call returns)
+  MIRT_HIP(ctx, hipMemcpyAsync(ctx->args.ptr, &args, sizeof(args), hipMemcpyHostToDevice, stream));
+  MIRT_HIP(ctx, launch_render(ctx->args.as<RenderArgs>(), count_work, cfg, stream));
+  if (time_kernels) MIRT_HIP(ctx, hipEventRecord(ev[1], stream));
+  MIRT_HIP(ctx, hipStreamSynchronize(stream));
   const auto t_end = std::chrono::steady_clock::now();
   if (stats) {
     stats->render_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
-    stats->iterations = iterations;
     stats->path_pool = pool;
+    WorkCounters w{};
+    MIRT_HIP(ctx, hipMemcpy(&w, ctx->work.ptr, sizeof(w), hipMemcpyDeviceToHost));
+    stats->iterations = w.rounds;
     if (count_work) {
-      WorkCounters w{};
-      MIRT_HIP(ctx, hipMemcpy(&w, ctx->work.ptr, sizeof(w), hipMemcpyDeviceToHost));
       stats->segments = w.segments;
       stats->nodes_visited = w.nodes;
       stats->prims_tested = w.prims;
-      if (std::getenv("MIRT_VERBOSE")) {
-        double lo = 1e30, hi = 0, sum = 0;
-        for (int b = 0; b < 256; ++b) {
-          const double ms = (double)w.block_busy[b] * 1e-5;
-          lo = std::min(lo, ms); hi = std::max(hi, ms); sum += ms;
-        }
-        std::fprintf(stderr, "mirt: extend blocks resident %.3f ms min, %.3f ms mean, %.3f ms max over the render\n", lo,
-                     sum / 256, hi);
-      }
       stats->node_wave_steps = w.wave_nodes;
       stats->prim_wave_steps = w.wave_prims;
-      for (int k = 0; k < MIRT_PHASE_COUNT; ++k) stats->extend_phase_cycles[k] = w.cycles[k];
+      for (int k = 0; k < MIRT_PHASE_COUNT; ++k) stats->phase_cycles[k] = w.cycles[k];
     }
     if (time_kernels) {
-      for (size_t i = 0; i + 3 < events.size(); i += 4) {
-        float ms = 0.0f;
-        MIRT_HIP(ctx, hipEventElapsedTime(&ms, events[i], events[i + 1]));
-        stats->kernel_ms[MIRT_KERNEL_EXTEND] += ms;
-        stats->kernel_launches[MIRT_KERNEL_EXTEND] += 1;
-        MIRT_HIP(ctx, hipEventElapsedTime(&ms, events[i + 2], events[i + 3]));
-        stats->kernel_ms[MIRT_KERNEL_SHADE] += ms;
-        stats->kernel_launches[MIRT_KERNEL_SHADE] += 1;
-      }
+      float ms = 0.0f;
+      MIRT_HIP(ctx, hipEventElapsedTime(&ms, ev[0], ev[1]));
+      stats->kernel_ms[MIRT_KERNEL_RENDER] = ms;
+      stats->kernel_launches[MIRT_KERNEL_RENDER] = 1;
     }
   }
   return MIRT_OK;

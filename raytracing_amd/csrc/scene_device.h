@@ -35,8 +35,8 @@ __host__ __device__ inline uint32_t make_material_word(uint32_t kind, uint32_t i
 // Traversal stack entries per lane (kept in LDS).  The host builder never
 // produces a tree taller than STACK_DEPTH - 2.
 constexpr int STACK_DEPTH = 32;
-constexpr int BLOCK_THREADS = 256;      // shade and trace
-constexpr int EXTEND_THREADS = 1024;    // extend: one block per region, a CU's worth of waves
+constexpr int BLOCK_THREADS = 256;      // trace
+constexpr int RENDER_THREADS = 1024;    // render: one block per region, a CU's worth of waves
 constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
 // BVH node, 64 bytes = 4 x float4:
@@ -130,37 +130,28 @@ struct DeviceScene {
 };
 
 // ---- the path pool ----------------------------------------------------------------
-// The pool is split into N_REGIONS equal regions of consecutive slots so that no counter is shared by
-// the whole GPU.  A region is the share of one extend block: the block keeps the region's queue
-// counters in LDS while it runs, shade compacts a region's survivors into the region's first slots
-// of the other buffer, and each region owns four material queues.
+// The pool is split into N_REGIONS equal regions of consecutive slots, one per block of the render kernel.
+// A region is private to its block: two buffers of path records (this round's and the next one's) and four
+// material queues of slot numbers.  The only thing the blocks share is the counter new paths are numbered from.
 constexpr uint32_t N_REGIONS = 256;
 constexpr uint32_t POOL_GRANULE = N_REGIONS * 64;  // a region is a whole number of waves
 
-// Per-iteration counters, double buffered by iteration parity; one 128-byte block per region.
-struct RegionCounters {
-  uint32_t n_cur;       // paths the region carries over from the previous iteration (filled by shade)
-  uint32_t pad0[3];
-  uint32_t queue_n[4];  // entries in the region's material queues (written by the region's extend block)
-  uint32_t pad1[24];
-};
-struct IterCounters {
-  uint64_t issued;  // camera paths started before this iteration
-  uint64_t pad[15];
-  RegionCounters region[N_REGIONS];
+struct RenderState {
+  unsigned long long issued;  // camera paths handed out so far (may run past the render's total)
+  unsigned long long pad[15];
 };
 
 struct WorkCounters {
   unsigned long long segments;
   unsigned long long nodes;
   unsigned long long prims;
-  unsigned long long pad;
+  unsigned int rounds;  // most start/walk/shade rounds any block went through
+  unsigned int pad;
   unsigned long long wave_nodes;  // wave-wide turns spent on tree steps / on primitive tests
   unsigned long long wave_prims;
-  // shader-clock cycles summed over waves, per phase of extend (instrumented build only):
-  // 0 load/generate, 1 inner-node loop, 2 primitive tests, 3 media, 4 write-back + binning, 5 whole kernel
+  // shader-clock cycles summed over waves, per phase of the render kernel (instrumented build only):
+  // 0 start paths + fetch rays, 1 tree steps, 2 primitive tests, 3 shade, 4 hand-in + binning, 5 whole kernel
   unsigned long long cycles[MIRT_PHASE_COUNT];
-  unsigned long long block_busy[256];  // 100 MHz ticks each extend block was resident, summed over launches
 };
 
 constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3, N_QUEUES = 4;
@@ -186,32 +177,40 @@ struct RenderConst {
 //   r2 = throughput.rgb, bits(sample index << 8 | bounce)
 //   r3 = t of the closest surface, bits(hit ref), bits(side of a box hit), -     (the only part extend writes
 //        for a surviving path)
-// Material queue q of region s holds slot numbers at queues[(q * N_REGIONS + s) * region_cap ...].
+// Material queue q of region s holds slot numbers (within the region) at queues[(s * N_QUEUES + q) * region_cap ...].
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
 constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
 // ---- launchers implemented in kernels.hip ------------------------------------
-// How extend is launched for a scene: one 1024-thread block per region, with nodes, primitive records and
-// wrapper chains staged in LDS when they fit beside the block's traversal stacks, else read from global memory.
-struct ExtendConfig {
-  bool lds_nodes;
+// How the render kernel is launched for a scene: one 1024-thread block per region, with nodes, primitive
+// records and wrapper chains staged in LDS when they fit beside the block's traversal stacks, else read from
+// global memory.
+struct RenderConfig {
+  bool lds_scene;
   int block;
   int grid;
   int stack_depth;
   size_t lds_bytes;
   uint32_t refill_min;  // a wave hands in finished rays and fetches new ones once this many lanes have none
-  uint32_t node_min;    // a wave steps down the tree while this many lanes hold an inner node, else tests primitives
+  uint32_t node_min;    // a wave keeps stepping down the tree while this many of its lanes hold an inner node
 };
-ExtendConfig plan_extend(const DeviceScene& sc);
-hipError_t launch_extend(const DeviceScene& sc, const RenderConst& rc, float4* cur, IterCounters* counters, int parity,
-                         WorkCounters* work, uint32_t* queues, bool count_work, const ExtendConfig& cfg,
-                         hipStream_t stream);
-void launch_shade(const DeviceScene& sc, const RenderConst& rc, const float4* cur, float4* next,
-                  IterCounters* counters, int parity, const uint32_t* queues, float* rgb_sum, int grid,
-                  hipStream_t stream);
+RenderConfig plan_render(const DeviceScene& sc);
+// Everything the render kernel is told, read by it from device memory.
+struct RenderArgs {
+  DeviceScene sc;
+  RenderConst rc;
+  float4* paths_a;   // the two buffers of path records, pool * 64 bytes each
+  float4* paths_b;
+  uint32_t* queues;  // pool * N_QUEUES slot numbers
+  RenderState* state;
+  WorkCounters* work;
+  float* rgb_sum;
+  uint32_t refill_min, node_min;
+};
+// `args` is a device pointer; the caller keeps it unchanged until the kernel has finished.
+hipError_t launch_render(const RenderArgs* args, bool count_work, const RenderConfig& cfg, hipStream_t stream);
 void launch_resolve(const float* rgb_sum, uint32_t n_values, uint32_t spp, uint8_t* rgb24, hipStream_t stream);
 void launch_trace(const DeviceScene& sc, const mirt_ray* rays, size_t n, uint32_t key0, uint32_t key1,
                   uint32_t* type_index, uint32_t* object_index, float* t, hipStream_t stream);
-int shade_blocks_per_cu();
 
 }  // namespace mirt
