@@ -668,32 +668,33 @@ __device__ __forceinline__ uint32_t f32_to_u32_sat(float v) {  // Rust `as u32`
 
 __device__ __forceinline__ V3 texture_color(const ShadeTables& sc, uint32_t tex, const Hit& h) {
   const V3 p = h.p;
-  for (int depth = 0; depth < 8; ++depth) {
-    const DTexture t = sc.textures[tex];
-    if (t.kind == MIRT_TEX_SOLID) {
-      return v3(t.r, t.g, t.b);
-    } else if (t.kind == MIRT_TEX_CHECKER) {  // texture.rs:51-60
-      const float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
-      tex = sines < 0.0f ? t.odd : t.even;
-    } else if (t.kind == MIRT_TEX_NOISE) {  // texture.rs:76-82
-      const float s = 1.0f + sinf(t.scale * p.z + 10.0f * perlin_turb2(sc, t.index, p));
-      return v3(1.0f, 1.0f, 1.0f) * 0.5f * s;
-    } else {  // texture.rs:101-122
-      const DImage im = sc.images[t.index];
-      float u = h.u, v = h.v;
-      if (h.sphere_uv) sphere_uv(h.on_sphere, u, v);
-      const float cu = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
-      const float cv = 1.0f - (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
-      uint32_t i = f32_to_u32_sat(cu * (float)im.width);
-      uint32_t j = f32_to_u32_sat(cv * (float)im.height);
-      if (i >= im.width) i = im.width - 1;
-      if (j >= im.height) j = im.height - 1;
-      const uint8_t* px = sc.image_data + im.offset + ((size_t)j * im.width + i) * 3;
-      const float scale = 1.0f / 255.0f;
-      return v3(scale * (float)px[0], scale * (float)px[1], scale * (float)px[2]);
-    }
+  DTexture t = sc.textures[tex];
+  // a checker has no colour of its own: it picks one of two textures by position (texture.rs:51-60)
+#pragma nounroll
+  for (int depth = 0; depth < 7 && t.kind == MIRT_TEX_CHECKER; ++depth) {
+    const float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
+    t = sc.textures[sines < 0.0f ? t.odd : t.even];
   }
-  return v3(0.0f, 0.0f, 0.0f);
+  if (t.kind == MIRT_TEX_SOLID) {
+    return v3(t.r, t.g, t.b);
+  } else if (t.kind == MIRT_TEX_NOISE) {  // texture.rs:76-82
+    const float s = 1.0f + sinf(t.scale * p.z + 10.0f * perlin_turb2(sc, t.index, p));
+    return v3(1.0f, 1.0f, 1.0f) * 0.5f * s;
+  } else if (t.kind == MIRT_TEX_IMAGE) {  // texture.rs:101-122
+    const DImage im = sc.images[t.index];
+    float u = h.u, v = h.v;
+    if (h.sphere_uv) sphere_uv(h.on_sphere, u, v);
+    const float cu = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+    const float cv = 1.0f - (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
+    uint32_t i = f32_to_u32_sat(cu * (float)im.width);
+    uint32_t j = f32_to_u32_sat(cv * (float)im.height);
+    if (i >= im.width) i = im.width - 1;
+    if (j >= im.height) j = im.height - 1;
+    const uint8_t* px = sc.image_data + im.offset + ((size_t)j * im.width + i) * 3;
+    const float scale = 1.0f / 255.0f;
+    return v3(scale * (float)px[0], scale * (float)px[1], scale * (float)px[2]);
+  }
+  return v3(0.0f, 0.0f, 0.0f);  // checkers nested deeper than the loop follows
 }
 
 // ---- sampling helpers (vec3.rs, onb.rs, pdf.rs) ------------------------------------
@@ -1142,8 +1143,12 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
           const Hit h = hit_record<PSTRIDE>(tb, sh.media, ref, r, t, __float_as_uint(r3.z));
           const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
           Rng rng = rng_begin(pixel, sample, bounce, STAGE_SHADE, rc.key0, rc.key1);
+          // the one texture lookup of the materials that have one (a light's only shows on its front side)
+          V3 att = v3(0.0f, 0.0f, 0.0f);
+          if (m.kind == MIRT_MAT_LAMBERTIAN || m.kind == MIRT_MAT_METAL ||
+              (m.kind == MIRT_MAT_DIFFUSE_LIGHT && h.front))
+            att = texture_color(sc, m.texture, h);
           if (m.kind == MIRT_MAT_LAMBERTIAN) {  // material.rs:39-58, renderer.rs:166-183
-            const V3 att = texture_color(sc, m.texture, h);
             const Onb uvw = onb_from_w(h.n);
             V3 dir;
             float pdf;
@@ -1166,7 +1171,6 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
           } else if (m.kind == MIRT_MAT_METAL) {  // material.rs:75-91
             const V3 reflected = reflect(unit(r.d), h.n);
             const V3 fuzz = m.param * random_in_unit_sphere(rng);
-            const V3 att = texture_color(sc, m.texture, h);
             beta = beta * att;
             nr.o = h.p; nr.d = reflected + fuzz; nr.time = r.time;
             alive = true;
@@ -1181,7 +1185,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
             nr.o = h.p; nr.time = r.time;
             alive = true;
           } else if (m.kind == MIRT_MAT_DIFFUSE_LIGHT) {  // material.rs:151-158
-            if (h.front) term = texture_color(sc, m.texture, h);
+            if (h.front) term = att;
           }
           // MIRT_MAT_ISOTROPIC: no scatter, no emission
         }

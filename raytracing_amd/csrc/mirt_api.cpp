@@ -511,7 +511,7 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   if (p.max_depth == 0) return MIRT_OK;  // renderer.rs:147-149: every sample is black
 
   // paths in flight: a whole number of chunks per region, no more than the render has paths
-  uint64_t want = p.path_pool ? p.path_pool : (1u << 21);
+  uint64_t want = p.path_pool ? p.path_pool : (1u << 23);
   want = std::min<uint64_t>(want, total);
   want = std::min<uint64_t>(std::max<uint64_t>(want, POOL_GRANULE), 1u << 27);
   const uint32_t pool = (uint32_t)((want + POOL_GRANULE - 1) / POOL_GRANULE * POOL_GRANULE);
