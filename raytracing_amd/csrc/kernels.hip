@@ -122,7 +122,7 @@ __device__ __forceinline__ uint4 as_uint4(float4 f) {
 struct SceneTables {
   const float4* nodes;
   const float4* prims;
-  const uint2* chains;
+  const float4* chains;  // two quads per chain, see ChainHead
   const float4* chain_ops;
 };
 // What shading reads besides the geometry: materials, textures and their tables, the lights to sample.
@@ -144,22 +144,41 @@ struct ShadeTables {
               (sc).lights,    (sc).light_groups, (sc).lights_mode, (sc).n_lights, (sc).n_light_groups}
 
 // ---- wrappers (transforms.rs) --------------------------------------------------
+// A chain's head says what the chain does when it is one of the common shapes -- an optional translate, an
+// optional rotation, an optional translate, in this order, by the offset and angle the head carries -- so
+// that applying it is straight-line code; any other chain (CHAIN_GENERIC) is a walk through its operations.
+constexpr uint32_t CHAIN_T_BEFORE = 1, CHAIN_ROTATE = 2, CHAIN_T_AFTER = 4, CHAIN_GENERIC = 8;
+struct ChainHead {
+  V3 offset;
+  float sin_t, cos_t;
+  uint32_t shape, first_op, n_ops;
+};
+__device__ __forceinline__ ChainHead chain_head(const SceneTables& tb, uint32_t chain) {
+  const float4 a = tb.chains[2 * (size_t)chain], b = tb.chains[2 * (size_t)chain + 1];
+  const uint32_t w = __float_as_uint(a.w);
+  return ChainHead{v3(a.x, a.y, a.z), b.x, b.y, w & 15u, w >> 12, (w >> 8) & 15u};
+}
+__device__ __forceinline__ void rotate_y(float s, float co, Ray& r) {  // transforms.rs:82-91
+  const float ox = co * r.o.x - s * r.o.z;
+  const float oz = s * r.o.x + co * r.o.z;
+  const float dx = co * r.d.x - s * r.d.z;
+  const float dz = s * r.d.x + co * r.d.z;
+  r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+}
 // Applies the wrappers of a chain to a ray, outermost first (transforms.rs:16, 82-91).
 __device__ __forceinline__ Ray chain_forward(const SceneTables& tb, uint32_t chain, Ray r) {
-  const uint2 c = tb.chains[chain];
-  for (uint32_t k = 0; k < c.y; ++k) {
-    const float4 op = tb.chain_ops[c.x + k];
-    const uint32_t kind = __float_as_uint(op.x);
-    if (kind == MIRT_OP_TRANSLATE) {
-      r.o = r.o - v3(op.y, op.z, op.w);
-    } else if (kind == MIRT_OP_ROTATE_Y) {
-      const float s = op.y, co = op.z;
-      const float ox = co * r.o.x - s * r.o.z;
-      const float oz = s * r.o.x + co * r.o.z;
-      const float dx = co * r.d.x - s * r.d.z;
-      const float dz = s * r.d.x + co * r.d.z;
-      r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+  const ChainHead h = chain_head(tb, chain);
+  if (h.shape & CHAIN_GENERIC) {
+    for (uint32_t k = 0; k < h.n_ops; ++k) {
+      const float4 op = tb.chain_ops[h.first_op + k];
+      const uint32_t kind = __float_as_uint(op.x);
+      if (kind == MIRT_OP_TRANSLATE) r.o = r.o - v3(op.y, op.z, op.w);
+      else if (kind == MIRT_OP_ROTATE_Y) rotate_y(op.y, op.z, r);
     }
+  } else {
+    if (h.shape & CHAIN_T_BEFORE) r.o = r.o - h.offset;
+    if (h.shape & CHAIN_ROTATE) rotate_y(h.sin_t, h.cos_t, r);
+    if (h.shape & CHAIN_T_AFTER) r.o = r.o - h.offset;
   }
   return r;
 }
@@ -549,26 +568,24 @@ __device__ __forceinline__ Hit hit_record(const SceneTables& tb, const MediumEnt
     chain = __float_as_uint(qc.x) >> 2;
     h.material_word = __float_as_uint(qc.z);
   }
-  // directions seen by each wrapper (after it transformed the ray)
+  // the ray as the primitive sees it, and the direction each wrapper saw (after it transformed the ray)
   V3 dir_at[MIRT_MAX_CHAIN_OPS];
   Ray r = world_ray;
-  uint2 c = make_uint2(0, 0);
+  ChainHead ch{};
   if (chain != 0) {
-    c = tb.chains[chain];
-    for (uint32_t k = 0; k < c.y && k < MIRT_MAX_CHAIN_OPS; ++k) {
-      const float4 op = tb.chain_ops[c.x + k];
-      const uint32_t kind = __float_as_uint(op.x);
-      if (kind == MIRT_OP_TRANSLATE) {
-        r.o = r.o - v3(op.y, op.z, op.w);
-      } else if (kind == MIRT_OP_ROTATE_Y) {
-        const float s = op.y, co = op.z;
-        const float ox = co * r.o.x - s * r.o.z;
-        const float oz = s * r.o.x + co * r.o.z;
-        const float dx = co * r.d.x - s * r.d.z;
-        const float dz = s * r.d.x + co * r.d.z;
-        r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
+    ch = chain_head(tb, chain);
+    if (ch.shape & CHAIN_GENERIC) {
+      for (uint32_t k = 0; k < ch.n_ops && k < MIRT_MAX_CHAIN_OPS; ++k) {
+        const float4 op = tb.chain_ops[ch.first_op + k];
+        const uint32_t kind = __float_as_uint(op.x);
+        if (kind == MIRT_OP_TRANSLATE) r.o = r.o - v3(op.y, op.z, op.w);
+        else if (kind == MIRT_OP_ROTATE_Y) rotate_y(op.y, op.z, r);
+        dir_at[k] = r.d;
       }
-      dir_at[k] = r.d;
+    } else {
+      if (ch.shape & CHAIN_T_BEFORE) r.o = r.o - ch.offset;
+      if (ch.shape & CHAIN_ROTATE) rotate_y(ch.sin_t, ch.cos_t, r);
+      if (ch.shape & CHAIN_T_AFTER) r.o = r.o - ch.offset;
     }
   }
   if (tag == TAG_MEDIUM) {  // transforms.rs:160-172
@@ -600,27 +617,36 @@ __device__ __forceinline__ Hit hit_record(const SceneTables& tb, const MediumEnt
     const float b0 = axis == 0 ? mn.y : mn.z, b1 = axis == 0 ? mx.y : mx.z;
     rect_record(axis, a0, a1, b0, b1, r, t_found, pa, pb, h);
   }
+  // back out through the wrappers, innermost first
+  auto undo_translate = [&](V3 offset, V3 d) {  // transforms.rs:18-19
+    h.p = h.p + offset;
+    h.front = dot(d, h.n) < 0.0f;
+  };
+  auto undo_rotate = [&](float s, float co, V3 d) {  // transforms.rs:94-105
+    V3 p = h.p, n = h.n;
+    p.x = co * h.p.x + s * h.p.z;
+    p.z = -s * h.p.x + co * h.p.z;
+    n.x = co * h.n.x + s * h.n.z;
+    n.z = -s * h.n.x + co * h.n.z;
+    h.p = p;
+    h.front = dot(d, n) < 0.0f;  // object-space direction, world-space normal
+    h.n = h.front ? n : -n;
+  };
   if (chain != 0) {
-    for (int k = (int)c.y - 1; k >= 0; --k) {
-      const float4 op = tb.chain_ops[c.x + k];
-      const uint32_t kind = __float_as_uint(op.x);
-      const V3 d = dir_at[k < MIRT_MAX_CHAIN_OPS ? k : 0];
-      if (kind == MIRT_OP_TRANSLATE) {  // transforms.rs:18-19
-        h.p = h.p + v3(op.y, op.z, op.w);
-        h.front = dot(d, h.n) < 0.0f;
-      } else if (kind == MIRT_OP_ROTATE_Y) {  // transforms.rs:94-105
-        const float s = op.y, co = op.z;
-        V3 p = h.p, n = h.n;
-        p.x = co * h.p.x + s * h.p.z;
-        p.z = -s * h.p.x + co * h.p.z;
-        n.x = co * h.n.x + s * h.n.z;
-        n.z = -s * h.n.x + co * h.n.z;
-        h.p = p;
-        h.front = dot(d, n) < 0.0f;  // object-space direction, world-space normal
-        h.n = h.front ? n : -n;
-      } else {  // transforms.rs:199-201
-        h.front = !h.front;
+    if (ch.shape & CHAIN_GENERIC) {
+      for (int k = (int)ch.n_ops - 1; k >= 0; --k) {
+        const float4 op = tb.chain_ops[ch.first_op + k];
+        const uint32_t kind = __float_as_uint(op.x);
+        const V3 d = dir_at[k < MIRT_MAX_CHAIN_OPS ? k : 0];
+        if (kind == MIRT_OP_TRANSLATE) undo_translate(v3(op.y, op.z, op.w), d);
+        else if (kind == MIRT_OP_ROTATE_Y) undo_rotate(op.y, op.z, d);
+        else h.front = !h.front;  // transforms.rs:199-201
       }
+    } else {
+      // r.d is the direction after the rotation (if any), world_ray.d the one before it
+      if (ch.shape & CHAIN_T_AFTER) undo_translate(ch.offset, r.d);
+      if (ch.shape & CHAIN_ROTATE) undo_rotate(ch.sin_t, ch.cos_t, r.d);
+      if (ch.shape & CHAIN_T_BEFORE) undo_translate(ch.offset, world_ray.d);
     }
   }
   return h;
@@ -902,16 +928,15 @@ struct RenderLds {
   float4* nodes;
   float4* prims;
   float4* ops;
-  uint2* chains;
+  float4* chains;  // two quads per chain
   Slot* stack;  // this thread's column; rows are RENDER_THREADS entries apart
   __device__ __forceinline__ RenderLds(float4* smem, ConstArgs A) {
     float4* after = smem + sizeof(RenderShared) / 16;
     nodes = after;
     prims = nodes + (LDS_SCENE ? A->sc.n_nodes * 4u : 0u);
     ops = prims + (LDS_SCENE ? A->sc.n_prims * PRIM_QUADS_LDS : 0u);
-    chains = reinterpret_cast<uint2*>(ops + (LDS_SCENE ? A->sc.n_chain_ops : 0u));
-    // chains are 8 bytes each: round up so the stack starts on a 16-byte boundary
-    stack = reinterpret_cast<Slot*>(chains + (LDS_SCENE ? ((A->sc.n_chains + 1u) & ~1u) : 0u)) + threadIdx.x;
+    chains = ops + (LDS_SCENE ? A->sc.n_chain_ops : 0u);
+    stack = reinterpret_cast<Slot*>(chains + (LDS_SCENE ? A->sc.n_chains * 2u : 0u)) + threadIdx.x;
   }
   // the tables the walk and the shading read the scene's geometry from
   __device__ __forceinline__ SceneTables tables(ConstArgs A) const {
@@ -1236,7 +1261,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     if (LDS_SCENE) {
       const RenderLds<true> lds(smem, A);
       const float4 *nodes = A->sc.nodes, *prims = A->sc.prims, *chain_ops = A->sc.chain_ops;
-      const uint2* chains = A->sc.chains;
+      const float4* chains = A->sc.chains;
       const uint32_t n_node_quads = A->sc.n_nodes * 4u, n_prim_quads = A->sc.n_prims * PRIM_QUADS_LDS;
       const uint32_t n_chain_ops = A->sc.n_chain_ops, n_chains = A->sc.n_chains;
       for (uint32_t k = threadIdx.x; k < n_node_quads; k += THREADS) {
@@ -1247,7 +1272,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       for (uint32_t k = threadIdx.x; k < n_prim_quads; k += THREADS)
         lds.prims[k] = prims[(k / PRIM_QUADS_LDS) * PRIM_QUADS + (k % PRIM_QUADS_LDS)];
       for (uint32_t k = threadIdx.x; k < n_chain_ops; k += THREADS) lds.ops[k] = chain_ops[k];
-      for (uint32_t k = threadIdx.x; k < n_chains; k += THREADS) lds.chains[k] = chains[k];
+      for (uint32_t k = threadIdx.x; k < n_chains * 2u; k += THREADS) lds.chains[k] = chains[k];
     }
   }
 
@@ -1393,7 +1418,7 @@ RenderConfig plan_render(const DeviceScene& sc) {
   // a stack entry per inner node on the path plus the pending sibling of the last one
   const int depth = (int)sc.bvh_height + 2;
   const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * PRIM_QUADS_LDS * 16 +
-                             (size_t)sc.n_chain_ops * 16 + (size_t)((sc.n_chains + 1u) & ~1u) * 8;
+                             (size_t)sc.n_chain_ops * 16 + (size_t)sc.n_chains * 32;
   // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes
   const size_t lds_total = sizeof(RenderShared) + scene_bytes + (size_t)depth * RENDER_THREADS * 2;
   if (lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {

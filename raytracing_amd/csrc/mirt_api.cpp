@@ -168,6 +168,7 @@ bool check_header(const mirt_scene_desc& d, const mirt_prim_header& h, std::stri
 
 int validate_desc(const mirt_scene_desc& d, std::string& why) {
   if (d.n_chains == 0 || !d.chains || d.chains[0].n_ops != 0) { why = "chains[0] must be the empty chain"; return MIRT_ERR_INVALID_ARGUMENT; }
+  if (d.n_chain_ops > (1u << 20)) { why = "more than 2^20 chain operations"; return MIRT_ERR_UNSUPPORTED; }
   for (uint32_t i = 0; i < d.n_chains; ++i) {
     if (d.chains[i].n_ops > MIRT_MAX_CHAIN_OPS) { why = "chain longer than MIRT_MAX_CHAIN_OPS"; return MIRT_ERR_UNSUPPORTED; }
     if ((uint64_t)d.chains[i].first_op + d.chains[i].n_ops > d.n_chain_ops) { why = "chain ops out of range"; return MIRT_ERR_INVALID_ARGUMENT; }
@@ -384,8 +385,34 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   MIRT_HIP(ctx, upload(s.prim_ids, ids));
 
   // ---- wrappers, media, materials, textures, lights ------------------------------------
-  std::vector<uint2> chains(d.n_chains);
-  for (uint32_t i = 0; i < d.n_chains; ++i) chains[i] = make_uint2(d.chains[i].first_op, d.chains[i].n_ops);
+  // Chain heads: a chain that is [translate][rotate][translate] with any of the three left out (and one offset)
+  // carries its numbers in the head, shape bits 1 | 2 | 4; anything else has shape 8 and is walked op by op.
+  std::vector<float4> chains(2 * (size_t)d.n_chains);
+  for (uint32_t i = 0; i < d.n_chains; ++i) {
+    const mirt_chain& c = d.chains[i];
+    uint32_t shape = 0;
+    float off[3] = {0, 0, 0}, sn = 0, cs = 0;
+    bool simple = true;
+    int stage = 0;  // 0 nothing yet, 1 after the first translate, 2 after the rotation, 3 after the last translate
+    for (uint32_t k = 0; k < c.n_ops && simple; ++k) {
+      const mirt_chain_op& op = d.chain_ops[c.first_op + k];
+      if (op.kind == MIRT_OP_TRANSLATE && stage == 0 ) {
+        shape |= 1; stage = 1; off[0] = op.p[0]; off[1] = op.p[1]; off[2] = op.p[2];
+      } else if (op.kind == MIRT_OP_TRANSLATE && stage == 2 && !(shape & 1)) {
+        shape |= 4; stage = 3; off[0] = op.p[0]; off[1] = op.p[1]; off[2] = op.p[2];
+      } else if (op.kind == MIRT_OP_ROTATE_Y && stage <= 1) {
+        shape |= 2; stage = 2; sn = op.p[0]; cs = op.p[1];
+      } else {
+        simple = false;
+      }
+    }
+    if (!simple) shape = 8;
+    const uint32_t word = shape | (c.n_ops << 8) | (c.first_op << 12);
+    float word_bits;
+    std::memcpy(&word_bits, &word, 4);
+    chains[2 * (size_t)i] = make_float4(off[0], off[1], off[2], word_bits);
+    chains[2 * (size_t)i + 1] = make_float4(sn, cs, 0.0f, 0.0f);
+  }
   std::vector<float4> ops(d.n_chain_ops);
   for (uint32_t i = 0; i < d.n_chain_ops; ++i) {
     float kind_bits;
@@ -452,7 +479,7 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   v.prim_ids = s.prim_ids.as<uint2>();
   v.n_prims = (uint32_t)build.size();
   v.n_chain_ops = d.n_chain_ops;
-  v.chains = s.chains.as<uint2>();
+  v.chains = s.chains.as<float4>();
   v.chain_ops = s.chain_ops.as<float4>();
   v.n_media = d.n_media;
   std::vector<DMedium> media(d.n_media);

@@ -109,7 +109,7 @@ struct DeviceScene {
   uint32_t n_prims;     // records a leaf can point at (boundary-only records come after them)
   uint32_t n_chain_ops;
 
-  const uint2* chains;      // (first_op, n_ops)
+  const float4* chains;     // two quads per chain: (offset.xyz, bits(shape | n_ops << 8 | first_op << 12)), (sin, cos, -, -)
   const float4* chain_ops;  // (bits(kind), p0, p1, p2)
 
   uint32_t n_media;
