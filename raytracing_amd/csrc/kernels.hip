@@ -390,31 +390,6 @@ __device__ __forceinline__ void prim_step(Walk& w, const SceneTables& tb, float 
   else w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
 }
 
-// Closest surface over (t_min, inf) of one ray, start to finish.  Two nested loops: a lane walks inner
-// nodes until it holds a leaf, the wave then tests the primitives its lanes hold together.
-template <bool COUNT, int PSTRIDE, bool COMPACT, class Slot>
-__device__ __forceinline__ void closest_surface(const SceneTables& tb, uint32_t root, const Ray& r,
-                                                float t_min, Slot* stack, uint32_t stride, uint32_t& best_ref,
-                                                float& best_t, uint32_t& best_material, uint32_t& best_face,
-                                                Work& work) {
-  Walk w;
-  walk_begin(w, r, root);
-  using RC = RefCode<COMPACT>;
-  for (;;) {
-    while (!(w.cur & RC::LEAF)) {
-      if (COUNT) ++work.nodes;
-      node_step<COMPACT>(w, tb, t_min, stack, stride);
-    }
-    if (w.cur == RC::NONE) break;
-    if (COUNT) ++work.prims;
-    prim_step<PSTRIDE, COMPACT>(w, tb, t_min, stack, stride);
-  }
-  best_ref = w.best_ref;
-  best_t = w.best_t;
-  best_material = w.best_material;
-  best_face = w.best_face;
-}
-
 // Both roots of the sphere quadratic (objects.rs:42-53), or false when the discriminant is negative.
 __device__ __forceinline__ bool sphere_roots(V3 center, float radius, const Ray& r, float& r1, float& r2) {
   const V3 os = r.o - center;
@@ -546,7 +521,7 @@ __device__ __forceinline__ void rect_record(uint32_t axis, float a0, float a1, f
   set_face(h, r, axis == 0 ? v3(0.0f, 0.0f, 1.0f) : (axis == 1 ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f)));
 }
 
-// Rebuilds the record of the hit that closest_surface / closest_media found
+// Rebuilds the record of the hit that the walk / closest_media found
 // at (ref, t), passing it through the wrappers inside-out as the nested
 // Hittable::hit calls of the reference do.
 // `face` is the side extend found for a box hit.
@@ -1241,6 +1216,78 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
   }
 }
 
+// Tracing caller-supplied rays uses the same kernel: these two stand in for start_paths and shade_queues.
+// Ray number g of the call goes into a free slot with g in the record's pixel field ...
+__device__ __noinline__ void start_rays(const RenderArgs* args, bool odd, uint32_t n_fresh, uint64_t first_new) {
+  ConstArgs A = pinned(args);
+  odd = uniform(odd) != 0;
+  n_fresh = uniform(n_fresh);
+  first_new = ((uint64_t)uniform((uint32_t)(first_new >> 32)) << 32) | uniform((uint32_t)first_new);
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)blockIdx.x * A->rc.region_cap;
+  const mirt_ray* const rays = A->rays;
+  for (uint32_t k = threadIdx.x; k < n_fresh; k += RENDER_THREADS) {
+    const uint64_t g = first_new + k;
+    const mirt_ray in = rays[g];
+    cur[4 * (size_t)k] = make_float4(in.origin[0], in.origin[1], in.origin[2], in.time);
+    cur[4 * (size_t)k + 1] = make_float4(in.direction[0], in.direction[1], in.direction[2], __uint_as_float((uint32_t)g));
+    cur[4 * (size_t)k + 2] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+  }
+}
+
+// ... and once the walk has found its closest surface (and the media had their chance, with the draws of
+// path (g, sample 0, bounce 0)), what it hit is written to the caller's arrays; no ray goes on.
+template <bool LDS_SCENE>
+__device__ __noinline__ void report_hits(const RenderArgs* args, bool odd) {
+  extern __shared__ float4 smem[];
+  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  ConstArgs A = pinned(args);
+  odd = uniform(odd) != 0;
+  const RenderLds<LDS_SCENE> lds(smem, A);
+  const SceneTables tb = lds.tables(A);
+  const SceneTables gt = MIRT_GLOBAL_TABLES(A->sc);
+  const uint32_t n_media = A->sc.n_media;
+  const DMedium* const media = A->sc.media;
+  const uint2* const prim_ids = A->sc.prim_ids;
+  const uint32_t key0 = A->rc.key0, key1 = A->rc.key1;
+  const uint32_t cap = A->rc.region_cap;
+  const float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)blockIdx.x * cap;
+  const uint32_t* const region_queues = A->queues + (size_t)blockIdx.x * N_QUEUES * cap;
+  uint32_t* const hit_type = A->hit_type;
+  uint32_t* const hit_object = A->hit_object;
+  float* const hit_t = A->hit_t;
+  for (uint32_t q = 0; q < N_QUEUES; ++q) {
+    const uint32_t n_q = sh.queue_n[q];
+    const uint32_t* entries = region_queues + (size_t)q * cap;
+    for (uint32_t e = threadIdx.x; e < n_q; e += RENDER_THREADS) {
+      const size_t i = entries[e];
+      const float4 r0 = cur[4 * i], r1 = cur[4 * i + 1], r3 = cur[4 * i + 3];
+      Ray r;
+      r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
+      const uint32_t g = __float_as_uint(r1.w);
+      float t = r3.x;
+      uint32_t ref = __float_as_uint(r3.y);
+      if (n_media != 0) {
+        uint32_t material = 0;
+        Rng rng = rng_begin(g, 0, 0, STAGE_MEDIA, key0, key1);
+        closest_media(n_media, tb, gt, sh.media, r, kTMin, rng, ref, t, material);
+      }
+      uint32_t ti = 0xFFFFFFFFu, oi = 0xFFFFFFFFu;
+      if (ref != REF_NONE) {
+        if (ref_tag(ref) == TAG_MEDIUM) {
+          ti = media[ref_index(ref)].type_index;
+          oi = media[ref_index(ref)].object_index;
+        } else {
+          const uint2 id = prim_ids[ref_index(ref)];
+          ti = id.x; oi = id.y;
+        }
+      }
+      hit_type[g] = ti;
+      hit_object[g] = oi;
+      hit_t[g] = ref != REF_NONE ? t : kInf;
+    }
+  }
+}
+
 // The whole render in one launch.  Block s owns region s of the path pool and stays resident until the
 // render is done: it stages the scene in LDS once, then goes round
 //   start   camera paths in the region's free slots, taking their numbers from a counter all blocks share,
@@ -1276,6 +1323,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     }
   }
 
+  const bool tracing = pinned(args)->rays != nullptr;  // caller-supplied rays instead of camera paths
   Work work{};
   long long k_begin = 0, ts = 0;
   if (COUNT) k_begin = clock64();
@@ -1311,13 +1359,15 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     ++rounds;
 
     if (COUNT) ts = clock64();
-    start_paths<COUNT>(args, odd, n_surv, n_fresh, ((uint64_t)sh.first_new_hi << 32) | sh.first_new_lo);
+    if (tracing) start_rays(args, odd, n_fresh, ((uint64_t)sh.first_new_hi << 32) | sh.first_new_lo);
+    else start_paths<COUNT>(args, odd, n_surv, n_fresh, ((uint64_t)sh.first_new_hi << 32) | sh.first_new_lo);
     if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
     __syncthreads();  // the new rays are visible to the whole block
     walk_rays<COUNT, LDS_SCENE>(args, odd, total, &work, &segments);
     __syncthreads();  // every live slot carries its surface hit and sits in one of the four queues
     if (COUNT) ts = clock64();
-    shade_queues<COUNT, LDS_SCENE>(args, odd);
+    if (tracing) report_hits<LDS_SCENE>(args, odd);
+    else shade_queues<COUNT, LDS_SCENE>(args, odd);
     if (COUNT) work.cycles[MIRT_PHASE_SHADE] += clock64() - ts;
     __syncthreads();
     n_surv = sh.n_next;
@@ -1364,48 +1414,6 @@ __global__ void k_resolve(const float* __restrict__ rgb_sum, uint32_t n_values, 
   else if (v >= 255.0f) out = 255;
   else out = (uint8_t)v;
   rgb24[i] = out;
-}
-
-// ---- trace: closest hit of caller-supplied rays ------------------------------------
-__global__ __launch_bounds__(BLOCK_THREADS) void k_trace(DeviceScene sc, const mirt_ray* __restrict__ rays, size_t n,
-                                                         uint32_t key0, uint32_t key1,
-                                                         uint32_t* __restrict__ type_index,
-                                                         uint32_t* __restrict__ object_index, float* __restrict__ t_out) {
-  __shared__ uint32_t stack_mem[STACK_DEPTH * BLOCK_THREADS];
-  __shared__ MediumEntry media[MIRT_MAX_MEDIA];
-  uint32_t* stack = stack_mem + threadIdx.x;
-  stage_media(sc.n_media, sc.media, sc.prims, media);
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * BLOCK_THREADS + threadIdx.x;
-  if (i >= n) return;
-  const mirt_ray in = rays[i];
-  Ray r;
-  r.o = v3(in.origin[0], in.origin[1], in.origin[2]);
-  r.d = v3(in.direction[0], in.direction[1], in.direction[2]);
-  r.time = in.time;
-  uint32_t ref, material, face;
-  float t;
-  Work work{};
-  const SceneTables tb = MIRT_GLOBAL_TABLES(sc);
-  closest_surface<false, (int)PRIM_QUADS, false>(tb, sc.root_ref, r, kTMin, stack, BLOCK_THREADS, ref, t, material, face,
-                                                 work);
-  if (sc.n_media != 0) {
-    Rng rng = rng_begin((uint32_t)i, 0, 0, STAGE_MEDIA, key0, key1);
-    closest_media(sc.n_media, tb, tb, media, r, kTMin, rng, ref, t, material);
-  }
-  uint32_t ti = 0xFFFFFFFFu, oi = 0xFFFFFFFFu;
-  if (ref != REF_NONE) {
-    if (ref_tag(ref) == TAG_MEDIUM) {
-      ti = sc.media[ref_index(ref)].type_index;
-      oi = sc.media[ref_index(ref)].object_index;
-    } else {
-      const uint2 id = sc.prim_ids[ref_index(ref)];
-      ti = id.x; oi = id.y;
-    }
-  }
-  type_index[i] = ti;
-  object_index[i] = oi;
-  t_out[i] = ref != REF_NONE ? t : kInf;
 }
 
 }  // namespace
@@ -1467,14 +1475,6 @@ void launch_resolve(const float* rgb_sum, uint32_t n_values, uint32_t spp, uint8
   const uint32_t block = 256;
   hipLaunchKernelGGL(k_resolve, dim3((n_values + block - 1) / block), dim3(block), 0, stream, rgb_sum, n_values, spp,
                      rgb24);
-}
-
-void launch_trace(const DeviceScene& sc, const mirt_ray* rays, size_t n, uint32_t key0, uint32_t key1,
-                  uint32_t* type_index, uint32_t* object_index, float* t, hipStream_t stream) {
-  if (n == 0) return;
-  const size_t grid = (n + BLOCK_THREADS - 1) / BLOCK_THREADS;
-  hipLaunchKernelGGL(k_trace, dim3((uint32_t)grid), dim3(BLOCK_THREADS), 0, stream, sc, rays, n, key0, key1,
-                     type_index, object_index, t);
 }
 
 }  // namespace mirt

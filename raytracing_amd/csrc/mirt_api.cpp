@@ -518,64 +518,40 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
 
 namespace {
 
-int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera, const mirt_render_params* params,
-                float* rgb_sum_device, hipStream_t stream, mirt_stats* stats) {
-  if (!scene || !camera || !params || !rgb_sum_device) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
-  const mirt_render_params& p = *params;
-  if (p.width < 2 || p.height < 2) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
-  if ((uint64_t)p.width * p.height >= (1ull << 31)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "image too large");
-  if (p.samples_per_pixel == 0) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be positive");
-  if ((uint64_t)p.first_sample + p.samples_per_pixel - 1 > MAX_SAMPLE_INDEX)
-    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sample index beyond 2^24 - 1");
-  if (p.max_depth > MAX_DEPTH_LIMIT) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "max_depth above 255");
-  if (!(camera->time0 <= camera->time1)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera time0 must be <= time1");
-  if (scene->has_moving && (camera->time0 < scene->time0 || camera->time1 > scene->time1))
-    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera shutter interval outside the scene's time range");
-  MIRT_HIP(ctx, hipSetDevice(ctx->device));
-  if (stats) std::memset(stats, 0, sizeof(*stats));
-  const uint64_t total = (uint64_t)p.width * p.height * p.samples_per_pixel;
-  if (stats) stats->samples = total;
-  if (p.max_depth == 0) return MIRT_OK;  // renderer.rs:147-149: every sample is black
+// What differs between a render and a trace of caller-supplied rays.
+struct Job {
+  RenderConst rc{};               // pool and region_cap are filled in by run_job
+  float* rgb_sum = nullptr;       // render
+  const mirt_ray* rays = nullptr; // trace
+  uint32_t* hit_type = nullptr;
+  uint32_t* hit_object = nullptr;
+  float* hit_t = nullptr;
+  uint64_t want_pool = 0;
+  uint32_t flags = 0;
+};
 
-  // paths in flight: a whole number of chunks per region, no more than the render has paths
-  uint64_t want = p.path_pool ? p.path_pool : (1u << 23);
+// Sizes the path pool, launches the render kernel once and waits for it.
+int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t stream, mirt_stats* stats) {
+  const uint64_t total = job.rc.total_paths;
+  // paths in flight: a whole number of waves per region, no more than the job has paths
+  uint64_t want = job.want_pool ? job.want_pool : (1u << 23);
   want = std::min<uint64_t>(want, total);
   want = std::min<uint64_t>(std::max<uint64_t>(want, POOL_GRANULE), 1u << 27);
   const uint32_t pool = (uint32_t)((want + POOL_GRANULE - 1) / POOL_GRANULE * POOL_GRANULE);
+  job.rc.pool = pool;
+  job.rc.region_cap = pool / N_REGIONS;
 
   MIRT_HIP(ctx, ctx->paths[0].ensure((size_t)pool * 64));
   MIRT_HIP(ctx, ctx->paths[1].ensure((size_t)pool * 64));
   MIRT_HIP(ctx, ctx->queues.ensure((size_t)pool * 4 * N_QUEUES));
   MIRT_HIP(ctx, ctx->state.ensure(sizeof(RenderState)));
   MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
+  MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
   MIRT_HIP(ctx, hipMemsetAsync(ctx->state.ptr, 0, sizeof(RenderState), stream));
   MIRT_HIP(ctx, hipMemsetAsync(ctx->work.ptr, 0, sizeof(WorkCounters), stream));
 
-  RenderConst rc{};
-  rc.cam = *camera;
-  rc.width = p.width;
-  rc.height = p.height;
-  rc.first_sample = p.first_sample;
-  rc.max_depth = p.max_depth;
-  rc.background[0] = p.background[0]; rc.background[1] = p.background[1]; rc.background[2] = p.background[2];
-  rc.key0 = (uint32_t)p.seed;
-  rc.key1 = (uint32_t)(p.seed >> 32);
-  rc.pool = pool;
-  rc.region_cap = pool / N_REGIONS;
-  rc.total_paths = total;
-  rc.n_groups = (uint32_t)(((uint64_t)p.width * p.height) / 64);
-  rc.group_stride = 1;
-  if (rc.n_groups > 1) {
-    // about 61 strides across the frame, the nearest one that is coprime to the group count
-    uint64_t stride = std::max<uint64_t>(1, rc.n_groups / 61);
-    stride = std::min<uint64_t>(stride, 0xFFFFFFFFull / rc.n_groups);
-    auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
-    while (stride > 1 && gcd(stride, rc.n_groups) != 1) --stride;
-    rc.group_stride = (uint32_t)stride;
-  }
-
-  const bool count_work = (p.flags & MIRT_RENDER_COUNT_WORK) != 0;
-  const bool time_kernels = (p.flags & MIRT_RENDER_TIME_KERNELS) != 0;
+  const bool count_work = (job.flags & MIRT_RENDER_COUNT_WORK) != 0;
+  const bool time_kernels = (job.flags & MIRT_RENDER_TIME_KERNELS) != 0;
   const RenderConfig cfg = plan_render(scene->view);
   if (std::getenv("MIRT_VERBOSE"))
     std::fprintf(stderr, "mirt: %zu prims, %u nodes, height %u; %s, %d x %d threads, %zu B LDS, stack %d; pool %u\n",
@@ -596,16 +572,19 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   const auto t_begin = std::chrono::steady_clock::now();
   RenderArgs args{};
   args.sc = scene->view;
-  args.rc = rc;
+  args.rc = job.rc;
   args.paths_a = ctx->paths[0].as<float4>();
   args.paths_b = ctx->paths[1].as<float4>();
   args.queues = ctx->queues.as<uint32_t>();
   args.state = ctx->state.as<RenderState>();
   args.work = ctx->work.as<WorkCounters>();
-  args.rgb_sum = rgb_sum_device;
+  args.rgb_sum = job.rgb_sum;
   args.refill_min = cfg.refill_min;
   args.node_min = cfg.node_min;
-  MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
+  args.rays = job.rays;
+  args.hit_type = job.hit_type;
+  args.hit_object = job.hit_object;
+  args.hit_t = job.hit_t;
   // (pageable source: the copy has left `args` by the time the call returns)
   MIRT_HIP(ctx, hipMemcpyAsync(ctx->args.ptr, &args, sizeof(args), hipMemcpyHostToDevice, stream));
   MIRT_HIP(ctx, launch_render(ctx->args.as<RenderArgs>(), count_work, cfg, stream));
@@ -634,6 +613,52 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
     }
   }
   return MIRT_OK;
+}
+
+int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera, const mirt_render_params* params,
+                float* rgb_sum_device, hipStream_t stream, mirt_stats* stats) {
+  if (!scene || !camera || !params || !rgb_sum_device) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  const mirt_render_params& p = *params;
+  if (p.width < 2 || p.height < 2) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
+  if ((uint64_t)p.width * p.height >= (1ull << 31)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "image too large");
+  if (p.samples_per_pixel == 0) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be positive");
+  if ((uint64_t)p.first_sample + p.samples_per_pixel - 1 > MAX_SAMPLE_INDEX)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sample index beyond 2^24 - 1");
+  if (p.max_depth > MAX_DEPTH_LIMIT) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "max_depth above 255");
+  if (!(camera->time0 <= camera->time1)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera time0 must be <= time1");
+  if (scene->has_moving && (camera->time0 < scene->time0 || camera->time1 > scene->time1))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera shutter interval outside the scene's time range");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const uint64_t total = (uint64_t)p.width * p.height * p.samples_per_pixel;
+  if (stats) stats->samples = total;
+  if (p.max_depth == 0) return MIRT_OK;  // renderer.rs:147-149: every sample is black
+
+  Job job;
+  RenderConst& rc = job.rc;
+  rc.cam = *camera;
+  rc.width = p.width;
+  rc.height = p.height;
+  rc.first_sample = p.first_sample;
+  rc.max_depth = p.max_depth;
+  rc.background[0] = p.background[0]; rc.background[1] = p.background[1]; rc.background[2] = p.background[2];
+  rc.key0 = (uint32_t)p.seed;
+  rc.key1 = (uint32_t)(p.seed >> 32);
+  rc.total_paths = total;
+  rc.n_groups = (uint32_t)(((uint64_t)p.width * p.height) / 64);
+  rc.group_stride = 1;
+  if (rc.n_groups > 1) {
+    // about 61 strides across the frame, the nearest one that is coprime to the group count
+    uint64_t stride = std::max<uint64_t>(1, rc.n_groups / 61);
+    stride = std::min<uint64_t>(stride, 0xFFFFFFFFull / rc.n_groups);
+    auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+    while (stride > 1 && gcd(stride, rc.n_groups) != 1) --stride;
+    rc.group_stride = (uint32_t)stride;
+  }
+  job.rgb_sum = rgb_sum_device;
+  job.want_pool = p.path_pool;
+  job.flags = p.flags;
+  return run_job(ctx, scene, job, stream, stats);
 }
 
 }  // namespace
@@ -690,14 +715,20 @@ int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!scene || (n && (!rays_device || !type_index_device || !object_index_device || !t_device)))
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
-  if (n >= (1ull << 31) * BLOCK_THREADS) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "too many rays");
+  if (n >= (1ull << 32)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "too many rays");
+  if (n == 0) return MIRT_OK;
   MIRT_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-  launch_trace(scene->view, rays_device, n, (uint32_t)seed, (uint32_t)(seed >> 32), type_index_device,
-               object_index_device, t_device, s);
-  MIRT_HIP(ctx, hipGetLastError());
-  MIRT_HIP(ctx, hipStreamSynchronize(s));
-  return MIRT_OK;
+  // the rays go through the render kernel's own walk, one round of it
+  Job job;
+  job.rc.key0 = (uint32_t)seed;
+  job.rc.key1 = (uint32_t)(seed >> 32);
+  job.rc.total_paths = n;
+  job.rc.max_depth = 1;
+  job.rays = rays_device;
+  job.hit_type = type_index_device;
+  job.hit_object = object_index_device;
+  job.hit_t = t_device;
+  return run_job(ctx, scene, job, stream ? (hipStream_t)stream : ctx->stream, nullptr);
 }
 
 int mirt_trace_primary(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,

@@ -206,11 +206,16 @@ struct RenderArgs {
   WorkCounters* work;
   float* rgb_sum;
   uint32_t refill_min, node_min;
+  // Tracing caller-supplied rays instead of rendering (rays != nullptr): rc.total_paths rays come from `rays`,
+  // each is walked once, and what ray g hit goes to hit_type[g], hit_object[g], hit_t[g].
+  const mirt_ray* rays;
+  uint32_t* hit_type;
+  uint32_t* hit_object;
+  float* hit_t;
 };
 // `args` is a device pointer; the caller keeps it unchanged until the kernel has finished.
 hipError_t launch_render(const RenderArgs* args, bool count_work, const RenderConfig& cfg, hipStream_t stream);
 void launch_resolve(const float* rgb_sum, uint32_t n_values, uint32_t spp, uint8_t* rgb24, hipStream_t stream);
-void launch_trace(const DeviceScene& sc, const mirt_ray* rays, size_t n, uint32_t key0, uint32_t key1,
-                  uint32_t* type_index, uint32_t* object_index, float* t, hipStream_t stream);
+
 
 }  // namespace mirt
