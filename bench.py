@@ -10,9 +10,9 @@ reduced to rank 0 over RCCL (only when N > 1) and rank 0 encodes the RGB24 image
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints one JSON line.  `roofline` prices the dominant kernel (extend: camera-ray
-generation + BVH traversal + material binning) from HIP-event durations taken inside the
-timed steps; `cpu_baseline` times the CPU oracle on a bounded sample of the same scene.
+Rank 0 prints one JSON line.  `roofline` prices the render kernel (one launch traces a whole
+step: camera paths, BVH walk, shading) from HIP-event durations taken inside the timed steps;
+`cpu_baseline` times the CPU oracle on a bounded sample of the same scene.
 """
 import argparse
 import json
@@ -44,6 +44,16 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--save", default="", help="write the last frame as PPM (rank 0)")
     return ap.parse_args()
+
+
+def measured_traffic(segments_per_launch):
+    """HBM bytes per launch from the committed counter run (FETCH_SIZE / WRITE_SIZE collected in separate
+    rocprofv3 --pmc passes over this workload, per segment), scaled to this launch; None without the file."""
+    f = ROOT / "profiles" / "hbm_traffic.json"
+    if not f.exists():
+        return None
+    m = json.loads(f.read_text())
+    return m["bytes_per_segment"] * segments_per_launch
 
 
 def cpu_baseline(scene, width, height, depth):
@@ -152,20 +162,18 @@ def main():
         roofline = None
         valu = None
         if kernel_launches[R.MIRT_KERNEL_RENDER]:
-            # One launch of k_render traces a whole step.  Algorithmic bytes per segment:
-            #   walk  : ray in (32 B), hit out (16 B), queue entry out (4 B), a 64-B node per tree step,
-            #           a 48-B primitive record per primitive test
-            #   shade : queue entry in (4 B), path record in (64 B), 48 B out for the paths that go on
-            #           (s - 1 of every s segments) or 12 B of radiance for the one that ends
-            #   start : 48 B of path record per camera path (1 of every s segments)
-            bytes_per_segment = 32 + 16 + 4 + 64 * n + 48 * p + 4 + 64 + 48 * (s - 1) / s + (12 + 48) / s
+            # One launch of k_render traces a whole step.  Algorithmic bytes per segment: 192 B of path state
+            # (ray, hit, throughput, queue entry, written once and read once per stage) + a 64-B node per tree
+            # step + a 32-B primitive record per primitive test.
+            bytes_per_segment = 192 + 64 * n + 32 * p
             my_segments = s * a.width * a.height * count * a.steps
             ker_s = kernel_ms[R.MIRT_KERNEL_RENDER] / 1e3
             achieved = my_segments * bytes_per_segment / ker_s / 1e9
             cyc = ws["phase_cycles"]
             names = ["start_fetch", "tree_steps", "primitive_tests", "shade", "hand_in", "total"]
             roofline = {"kernel": "k_render", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": measured_traffic(my_segments / kernel_launches[R.MIRT_KERNEL_RENDER]),
                         "avg_launch_ms": kernel_ms[R.MIRT_KERNEL_RENDER] / kernel_launches[R.MIRT_KERNEL_RENDER],
                         "launches": kernel_launches[R.MIRT_KERNEL_RENDER],
                         "bytes_per_segment": bytes_per_segment,
@@ -174,8 +182,9 @@ def main():
                         "lanes_at_work": {"tree_steps": ws["nodes_visited"] / max(1, 64 * ws["node_wave_steps"]),
                                           "primitive_tests": ws["prims_tested"] / max(1, 64 * ws["prim_wave_steps"])},
                         "wave_time_share": {k: cyc[i] / max(1, cyc[5]) for i, k in enumerate(names[:5])}}
-            # two padded slab tests per tree step (2 x 32 flops), ~26 flops per primitive test; shading not counted
-            flops_per_segment = 64 * n + 26 * p
+            # two slab tests per tree step (44 flops), ~26 per primitive test, ~160 to shade a hit,
+            # three Philox4x32-10 blocks of ~100 integer operations
+            flops_per_segment = 44 * n + 26 * p + 160 + 3 * 100
             tf = my_segments * flops_per_segment / ker_s / 1e12
             valu = {"kernel": "k_render", "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": tf / VALU_PEAK_TFLOPS, "flops_per_segment": flops_per_segment}

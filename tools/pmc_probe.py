@@ -9,4 +9,4 @@ name = sys.argv[1] if len(sys.argv) > 1 else "final_scene"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 g = R.ExampleScene(name)
 _, _, st = g.render(1920, 1080, spp, aspect=1920 / 1080)
-print(name, spp, "spp", st["iterations"], "iterations", round(st["render_ms"], 2), "ms")
+print(name, spp, "spp", st["iterations"], "rounds", round(st["render_ms"], 2), "ms")
