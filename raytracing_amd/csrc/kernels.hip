@@ -876,7 +876,8 @@ struct RenderShared {
   uint32_t next_work;                   // next slot to hand out to the walk
   uint32_t queue_n[N_QUEUES];           // entries in the region's material queues
   uint32_t n_next;                      // survivors written to the other buffer so far
-  uint32_t pad[3];
+  uint32_t shade_next;                  // next batch of 64 queue entries to hand out to a shading wave
+  uint32_t pad[2];
   MediumEntry media[MIRT_MAX_MEDIA];
 };
 static_assert(sizeof(RenderShared) % 16 == 0, "keeps the node array 16-byte aligned");
@@ -1049,6 +1050,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_
         ++segments;
       }
       if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_WRITE] += now - ts; ts = now; }
+      // (the lanes refilled together get consecutive slots: new camera paths of one pixel tile, which walk
+      // the tree together)
       if (more) {
         more = base + n_out < total;
         const uint32_t entry = base + (uint32_t)__popcll(m_out & ((1ull << lane) - 1ull));
@@ -1088,7 +1091,6 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_
 // scatters or ends the path, survivors are packed into the first slots of the region's other buffer.
 template <bool COUNT, bool LDS_SCENE>
 __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
-  constexpr int THREADS = RENDER_THREADS;
   extern __shared__ float4 smem[];
   RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
   constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
@@ -1098,7 +1100,6 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
   const SceneTables tb = lds.tables(A);
   const uint32_t region = blockIdx.x;
   const uint32_t lane = lane_id();
-  const uint32_t wave = uniform(threadIdx.x >> 6);
   const ShadeTables sc = MIRT_SHADE_TABLES(A->sc);
   const SceneTables gt = MIRT_GLOBAL_TABLES(A->sc);
   const uint32_t n_media = A->sc.n_media;
@@ -1110,10 +1111,21 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
   float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
   const uint32_t* const region_queues = A->queues + (size_t)region * N_QUEUES * cap;
   float* const rgb_sum = A->rgb_sum;
-  for (uint32_t q = 0; q < N_QUEUES; ++q) {
-    const uint32_t n_q = sh.queue_n[q];
-    const uint32_t* entries = region_queues + (size_t)q * cap;
-    for (uint32_t e0 = wave * 64u; e0 < n_q; e0 += THREADS) {  // a wave shades 64 entries of one queue
+  // The four queues are cut into batches of 64 entries, numbered queue after queue; a wave takes the next
+  // batch whenever it has finished one, so no wave is left with the expensive ones.
+  const uint32_t n0 = sh.queue_n[0], n1 = sh.queue_n[1], n2 = sh.queue_n[2], n3 = sh.queue_n[3];
+  const uint32_t b1 = (n0 + 63u) >> 6, b2 = b1 + ((n1 + 63u) >> 6), b3 = b2 + ((n2 + 63u) >> 6);
+  const uint32_t n_batches = b3 + ((n3 + 63u) >> 6);
+  {
+    for (;;) {
+      uint32_t batch = 0;
+      if (lane == 0) batch = atomicAdd(&sh.shade_next, 1u);
+      batch = uniform(batch);
+      if (batch >= n_batches) break;
+      const uint32_t q = batch < b1 ? 0u : (batch < b2 ? 1u : (batch < b3 ? 2u : 3u));
+      const uint32_t n_q = q == 0 ? n0 : (q == 1 ? n1 : (q == 2 ? n2 : n3));
+      const uint32_t e0 = (batch - (q == 0 ? 0u : (q == 1 ? b1 : (q == 2 ? b2 : b3)))) << 6;
+      const uint32_t* entries = region_queues + (size_t)q * cap;
       const uint32_t e = e0 + lane;
       bool alive = false;
       Ray nr;
@@ -1350,6 +1362,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       sh.next_work = 0;
       sh.queue_n[0] = 0; sh.queue_n[1] = 0; sh.queue_n[2] = 0; sh.queue_n[3] = 0;
       sh.n_next = 0;
+      sh.shade_next = 0;
     }
     __syncthreads();  // also: the staged scene is complete before the first walk
     const uint32_t n_fresh = sh.n_fresh;
