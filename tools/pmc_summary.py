@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            k = "k_extend" if "k_extend" in k else "k_shade" if "k_shade" in k else None
+            k = "k_render" if "k_render" in k else None
             if not k:
                 continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
