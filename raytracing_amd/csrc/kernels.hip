@@ -76,8 +76,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
                                                uint32_t k1) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one 32 x 32 -> 64 multiply gives both halves of a product (v_mad_u64_u32)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     c0 = hi1 ^ c1 ^ k0;
     c1 = lo1;
     c2 = hi0 ^ c3 ^ k1;
@@ -264,14 +266,15 @@ __device__ __forceinline__ bool record_t(const SceneTables& tb, uint32_t index, 
   order = __float_as_uint(qc.y);
   material = __float_as_uint(qc.z);
   const uint32_t chain = chain_tag >> 2;
-  if (tag == TAG_SPHERE) {
-    if (chain != 0) return sphere_t(xyz(qa), qa.w, chain_forward(tb, chain, r), t_min, t_max, t);
-    return sphere_t(xyz(qa), qa.w, r, t_min, t_max, t);
-  }
-  const float4 qb = p[1];
+  float4 qb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (tag != TAG_SPHERE) qb = p[1];
   const Ray lr = chain != 0 ? chain_forward(tb, chain, r) : r;
-  if (tag == TAG_MOVING_SPHERE) {
-    return sphere_t(moving_center(qa, qb, qc.w, lr.time), qa.w, lr, t_min, t_max, t);
+  if (tag <= TAG_MOVING_SPHERE) {
+    // one copy of the sphere test serves fixed and moving spheres, wrapped or not: the lanes of a wave that
+    // hold any of them run it together
+    V3 center = xyz(qa);
+    if (tag == TAG_MOVING_SPHERE) center = moving_center(qa, qb, qc.w, lr.time);
+    return sphere_t(center, qa.w, lr, t_min, t_max, t);
   } else if (tag == TAG_RECT) {
     float pa, pb;
     const bool ok = rect_t(__float_as_uint(qb.y), qa.x, qa.y, qa.z, qa.w, qb.x, lr, t_min, t_max, t, pa, pb);
@@ -569,27 +572,21 @@ __device__ __forceinline__ Hit hit_record(const SceneTables& tb, const MediumEnt
     h.n = v3(1.0f, 0.0f, 0.0f);
     h.u = 0.0f; h.v = 0.0f;
     h.front = true;
-  } else if (tag == TAG_SPHERE) {
+  } else if (tag <= TAG_MOVING_SPHERE) {
     const float4 g = rec[0];
-    sphere_record(xyz(g), g.w, r, t_found, h);
-  } else if (tag == TAG_MOVING_SPHERE) {
-    const float4 m0 = rec[0], m1 = rec[1];
-    sphere_record(moving_center(m0, m1, rec[2].w, r.time), m0.w, r, t_found, h);
-  } else if (tag == TAG_RECT) {
+    V3 center = xyz(g);
+    if (tag == TAG_MOVING_SPHERE) center = moving_center(g, rec[1], rec[2].w, r.time);
+    sphere_record(center, g.w, r, t_found, h);
+  } else {
+    // a rect, or the side of a box the walk found (one of its six rects, objects.rs:396-436): one copy of the code
     const float4 g0 = rec[0], g1 = rec[1];
-    const uint32_t axis = __float_as_uint(g1.y);
+    const bool is_rect = tag == TAG_RECT;
+    const uint32_t axis = is_rect ? __float_as_uint(g1.y) : face >> 1;
+    const float a0 = is_rect ? g0.x : (axis == 2 ? g0.y : g0.x), a1 = is_rect ? g0.y : (axis == 2 ? g1.y : g1.x);
+    const float b0 = is_rect ? g0.z : (axis == 0 ? g0.y : g0.z), b1 = is_rect ? g0.w : (axis == 0 ? g1.y : g1.z);
     // where the ray meets the rect's plane, as the hit test worked it out (objects.rs:212-213)
     const float pa = axis == 2 ? r.o.y + t_found * r.d.y : r.o.x + t_found * r.d.x;
     const float pb = axis == 0 ? r.o.y + t_found * r.d.y : r.o.z + t_found * r.d.z;
-    rect_record(axis, g0.x, g0.y, g0.z, g0.w, r, t_found, pa, pb, h);
-  } else {
-    const float4 g0 = rec[0], g1 = rec[1];
-    const V3 mn = xyz(g0), mx = xyz(g1);
-    const uint32_t axis = face >> 1;  // the side of the box is one of its six rects (objects.rs:396-436)
-    const float pa = axis == 2 ? r.o.y + t_found * r.d.y : r.o.x + t_found * r.d.x;
-    const float pb = axis == 0 ? r.o.y + t_found * r.d.y : r.o.z + t_found * r.d.z;
-    const float a0 = axis == 2 ? mn.y : mn.x, a1 = axis == 2 ? mx.y : mx.x;
-    const float b0 = axis == 0 ? mn.y : mn.z, b1 = axis == 0 ? mx.y : mx.z;
     rect_record(axis, a0, a1, b0, b1, r, t_found, pa, pb, h);
   }
   // back out through the wrappers, innermost first
@@ -1451,7 +1448,7 @@ RenderConfig plan_render(const DeviceScene& sc) {
     cfg.stack_depth = STACK_DEPTH;
     cfg.lds_bytes = sizeof(RenderShared) + (size_t)STACK_DEPTH * RENDER_THREADS * 4;
   }
-  cfg.refill_min = 16;
+  cfg.refill_min = 32;
   cfg.node_min = 16;
   if (const char* e = std::getenv("MIRT_REFILL_MIN")) {  // tuning aids
     const long v = std::strtol(e, nullptr, 10);
