@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -49,6 +50,7 @@ struct Builder {
   std::vector<BuildPrim>& prims;
   std::vector<HostNode>& nodes;
   uint32_t leaf_max;
+  float step_cost;  // cost of one more step down the tree, in primitive tests
 
   Child make_leaf(size_t lo, size_t hi) const {
     Child c;
@@ -117,7 +119,7 @@ struct Builder {
       }
       // a small group stays one leaf when splitting it would not pay: one more node step against the
       // primitive tests the children's smaller boxes would save (a node step costs about one test)
-      if (n <= leaf_max && best_axis >= 0 && !(best_cost / std::max(all.half_area(), 1e-30f) + 1.0f < (float)n))
+      if (n <= leaf_max && best_axis >= 0 && !(best_cost / std::max(all.half_area(), 1e-30f) + step_cost < (float)n))
         return make_leaf(lo, hi);
       if (best_axis >= 0) {
         const float extent = cb.mx[best_axis] - cb.mn[best_axis];
@@ -173,7 +175,9 @@ BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t 
   BuiltBvh out;
   if (prims.empty()) return out;
   out.nodes.reserve(prims.size());
-  Builder b{prims, out.nodes, std::max(1u, std::min(leaf_max, 8u))};
+  float step_cost = 1.0f;
+  if (const char* e = std::getenv("MIRT_STEP_COST")) step_cost = (float)std::atof(e);  // tuning aid
+  Builder b{prims, out.nodes, std::max(1u, std::min(leaf_max, 8u)), step_cost};
   const Child root = b.build(0, prims.size(), max_height + 1);
   out.root_ref = root.ref;
   out.height = root.height;

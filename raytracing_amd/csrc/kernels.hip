@@ -842,12 +842,17 @@ __device__ __forceinline__ int queue_of(uint32_t material_word) {
 
 // Pixel of path number `idx` within one sample pass: 8-row bands walked column
 // by column, so the 64 lanes of a wave cover an 8x8 pixel tile.
-__device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t height, uint32_t& x, uint32_t& y) {
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv f) {
+  const uint32_t t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+__device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t height, FastDiv by_band, uint32_t& x,
+                                         uint32_t& y) {
   const uint32_t band_size = width * 8u;
-  const uint32_t band = idx / band_size;
+  const uint32_t band = fast_div(idx, by_band);
   const uint32_t in_band = idx - band * band_size;
   const uint32_t rows = min(8u, height - band * 8u);
-  x = in_band / rows;
+  x = rows == 8u ? in_band >> 3 : in_band / rows;  // only the frame's last band can be lower
   y = band * 8u + (in_band - x * rows);
 }
 
@@ -944,17 +949,27 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
   const V3 ver = v3(A->rc.cam.vertical[0], A->rc.cam.vertical[1], A->rc.cam.vertical[2]);
   const float lens_radius = A->rc.cam.lens_radius, time0 = A->rc.cam.time0, time1 = A->rc.cam.time1;
   const uint32_t pixels = width * height;
+  const FastDiv by_pixels{A->rc.by_pixels.m, A->rc.by_pixels.sh1, A->rc.by_pixels.sh2};
+  const FastDiv by_groups{A->rc.by_groups.m, A->rc.by_groups.sh1, A->rc.by_groups.sh2};
+  const FastDiv by_band{A->rc.by_band.m, A->rc.by_band.sh1, A->rc.by_band.sh2};
+  // path number = pass * pixels + place in the pass; the one long division is done once for the block
+  const uint32_t first_pass = (uint32_t)(first_new / pixels);
+  const uint32_t first_place = (uint32_t)(first_new - (uint64_t)first_pass * pixels);
   for (uint32_t k = threadIdx.x; k < n_fresh; k += THREADS) {
     const size_t i = n_surv + k;
-    const uint64_t g = first_new + k;
-    const uint32_t pass = (uint32_t)(g / pixels);
-    uint32_t in_pass = (uint32_t)(g - (uint64_t)pass * pixels);
+    const uint32_t place = first_place + k;  // < 2^31 + 2^27
+    const uint32_t more_passes = fast_div(place, by_pixels);
+    const uint32_t pass = first_pass + more_passes;
+    uint32_t in_pass = place - more_passes * pixels;
     // Consecutive groups of 64 paths start far apart in the image, so that every region's new paths are
     // a sample of the whole frame and the regions cost about the same to trace.
     const uint32_t group = in_pass >> 6;
-    if (group < n_groups) in_pass = (((group * group_stride) % n_groups) << 6) | (in_pass & 63u);
+    if (group < n_groups) {
+      const uint32_t scaled = group * group_stride;
+      in_pass = ((scaled - fast_div(scaled, by_groups) * n_groups) << 6) | (in_pass & 63u);
+    }
     uint32_t x, y;
-    pixel_of(in_pass, width, height, x, y);
+    pixel_of(in_pass, width, height, by_band, x, y);
     const uint32_t pixel = y * width + x;
     const uint32_t sample = first_sample + pass;
     Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, key0, key1);
@@ -1100,9 +1115,10 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
   const ShadeTables sc = MIRT_SHADE_TABLES(A->sc);
   const SceneTables gt = MIRT_GLOBAL_TABLES(A->sc);
   const uint32_t n_media = A->sc.n_media;
-  struct { uint32_t width, height, max_depth, key0, key1; float background[3]; }
+  struct { uint32_t width, height, max_depth, key0, key1; float background[3]; FastDiv by_width; }
       rc{A->rc.width, A->rc.height, A->rc.max_depth, A->rc.key0, A->rc.key1,
-         {A->rc.background[0], A->rc.background[1], A->rc.background[2]}};
+         {A->rc.background[0], A->rc.background[1], A->rc.background[2]},
+         {A->rc.by_width.m, A->rc.by_width.sh1, A->rc.by_width.sh2}};
   const uint32_t cap = A->rc.region_cap;
   const float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
   float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
@@ -1206,7 +1222,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
           // pixel as in the reference (renderer.rs:241-252: NaN as u8 == 0)
           const V3 cval = beta * term;
           if (!(cval.x == 0.0f && cval.y == 0.0f && cval.z == 0.0f)) {
-            const uint32_t y = pixel / rc.width, x = pixel - y * rc.width;
+            const uint32_t y = fast_div(pixel, rc.by_width), x = pixel - y * rc.width;
             float* dst = rgb_sum + ((size_t)(rc.height - 1 - y) * rc.width + x) * 3;
             atomicAdd(dst, cval.x);
             atomicAdd(dst + 1, cval.y);

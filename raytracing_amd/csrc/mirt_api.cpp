@@ -363,7 +363,12 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
 
   // ---- acceleration structure ----------------------------------------------------
   s.n_prims = build.size();
-  BuiltBvh bvh = build_bvh(build, STACK_DEPTH - 2, LEAF_MAX_PRIMS);
+  uint32_t leaf_max = LEAF_MAX_PRIMS;
+  if (const char* e = std::getenv("MIRT_LEAF_MAX")) {  // tuning aid
+    const long v = std::strtol(e, nullptr, 10);
+    if (v >= 1 && v <= 8) leaf_max = (uint32_t)v;
+  }
+  BuiltBvh bvh = build_bvh(build, STACK_DEPTH - 2, leaf_max);
   if (bvh.height > (uint32_t)STACK_DEPTH - 1) return fail(ctx, MIRT_ERR_UNSUPPORTED, "BVH taller than the traversal stack");
   s.bvh_height = bvh.height;
   MIRT_HIP(ctx, upload(s.nodes, bvh.nodes));
@@ -655,6 +660,10 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
     while (stride > 1 && gcd(stride, rc.n_groups) != 1) --stride;
     rc.group_stride = (uint32_t)stride;
   }
+  rc.by_pixels = make_fastdiv(p.width * p.height);
+  rc.by_groups = make_fastdiv(std::max(1u, rc.n_groups));
+  rc.by_band = make_fastdiv(p.width * 8u);
+  rc.by_width = make_fastdiv(p.width);
   job.rgb_sum = rgb_sum_device;
   job.want_pool = p.path_pool;
   job.flags = p.flags;

@@ -156,6 +156,18 @@ struct WorkCounters {
 
 constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3, N_QUEUES = 4;
 
+// Division of a 32-bit number by a divisor fixed for the whole launch: a multiply-high and two shifts in
+// place of the long sequence a division compiles to (Granlund & Montgomery, unsigned case).
+struct FastDiv {
+  uint32_t m, sh1, sh2;
+};
+inline FastDiv make_fastdiv(uint32_t d) {  // d >= 1
+  uint32_t l = 0;
+  while (l < 32 && (1ull << l) < d) ++l;
+  const uint64_t m = ((((1ull << l) - d) << 32) / d) + 1;
+  return FastDiv{(uint32_t)m, l < 1 ? l : 1u, l > 0 ? l - 1 : 0u};
+}
+
 struct RenderConst {
   mirt_camera cam;
   uint32_t width, height;
@@ -169,6 +181,7 @@ struct RenderConst {
   // Order in which a pass walks the image: group j of 64 pixels (of the n_groups whole groups) is visited
   // as number (j * group_stride) % n_groups; group_stride is coprime to n_groups and their product < 2^32.
   uint32_t n_groups, group_stride;
+  FastDiv by_pixels, by_groups, by_band, by_width;  // / (width*height), / n_groups, / (8*width), / width
 };
 
 // Path record, 64 bytes = 4 x float4:
