@@ -1,24 +1,21 @@
 // gfx950 kernels of the wavefront path tracer.
 //
-//   extend  : starts new camera paths in the free tail of the path buffer
-//             (renderer.rs:215-218, camera.rs:57-68), finds the closest hit of
-//             every path's current segment (world.rs:75-94 / bvh.rs:148-152)
-//             and bins the path by the material it hit
-//   shade   : one lane per binned path, material by material: rebuilds the hit
-//             record, evaluates emit / scatter / pdfs (renderer.rs:150-189),
-//             adds finished paths into the image sums and compacts the
-//             survivors into the other path buffer
-//   resolve : renderer.rs:232-259
-//   trace   : closest hit of caller-supplied rays
+//   k_render  : the whole render in one launch.  Every block owns a region of the path pool and goes round
+//                 start  new camera paths in the region's free slots (renderer.rs:215-218, camera.rs:57-68)
+//                 walk   every live ray to its closest surface (world.rs:75-94 / bvh.rs:148-152) and file the
+//                        path under the material it hit
+//                 shade  material by material: media, hit record, emit / scatter / pdfs (renderer.rs:150-189);
+//                        finished paths go into the image sums, survivors into the region's other buffer
+//               until the frame is done.  Tracing caller-supplied rays is the same kernel with its first and
+//               last phase swapped for a load and a store.
+//   k_resolve : renderer.rs:232-259
 //
-// Built with -ffp-contract=off: the intersection arithmetic has to round
-// exactly like the scalar f32 code of the reference.  Where a fused multiply
-// add is harmless (the conservative box test) it is written explicitly.
+// Built with -ffp-contract=off: the intersection arithmetic has to round exactly like the scalar f32 code of
+// the reference.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 #include <type_traits>
-
 
 #include "scene_device.h"
 
@@ -116,9 +113,6 @@ __device__ __forceinline__ float rng_at(Rng& r, uint32_t index) {  // uniform in
 __device__ __forceinline__ float rng_next(Rng& r) { return rng_at(r, r.next++); }
 __device__ __forceinline__ float rng_range(Rng& r, float lo, float hi) { return lo + (hi - lo) * rng_next(r); }
 
-__device__ __forceinline__ uint4 as_uint4(float4 f) {
-  return make_uint4(__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w));
-}
 // Where the traversal reads nodes, primitive records and wrapper chains from: the block's LDS copies
 // or global memory.  PSTRIDE (template parameter of the users) is the record stride in float4s.
 struct SceneTables {
@@ -527,7 +521,7 @@ __device__ __forceinline__ void rect_record(uint32_t axis, float a0, float a1, f
 // Rebuilds the record of the hit that the walk / closest_media found
 // at (ref, t), passing it through the wrappers inside-out as the nested
 // Hittable::hit calls of the reference do.
-// `face` is the side extend found for a box hit.
+// `face` is the side the walk found for a box hit.
 template <int PSTRIDE>
 __device__ __forceinline__ Hit hit_record(const SceneTables& tb, const MediumEntry* media, uint32_t ref,
                                           const Ray& world_ray, float t_found, uint32_t face) {
@@ -840,12 +834,12 @@ __device__ __forceinline__ int queue_of(uint32_t material_word) {
                                        : QUEUE_TERMINATE;
 }
 
-// Pixel of path number `idx` within one sample pass: 8-row bands walked column
-// by column, so the 64 lanes of a wave cover an 8x8 pixel tile.
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv f) {
   const uint32_t t = __umulhi(f.m, n);
   return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
+// Pixel of place `idx` within one sample pass: 8-row bands walked column
+// by column, so 64 consecutive places cover an 8x8 pixel tile.
 __device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t height, FastDiv by_band, uint32_t& x,
                                          uint32_t& y) {
   const uint32_t band_size = width * 8u;
@@ -854,18 +848,6 @@ __device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t 
   const uint32_t rows = min(8u, height - band * 8u);
   x = rows == 8u ? in_band >> 3 : in_band / rows;  // only the frame's last band can be lower
   y = band * 8u + (in_band - x * rows);
-}
-
-// Exclusive prefix sum over the 64 lanes of a wave; `total` receives the sum.
-__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& total) {
-  uint32_t inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t up = __shfl_up(inc, off);
-    if ((int)lane_id() >= off) inc += up;
-  }
-  total = __shfl(inc, 63);
-  return inc - v;
 }
 
 // ---- render -----------------------------------------------------------------------

@@ -1,6 +1,6 @@
 // C ABI of the MI355X path-tracing backend (include/mirt.h): context, scene
-// upload (lowered arrays -> device buffers + BVH) and the host loop that
-// drives the extend/shade kernels.
+// upload (lowered arrays -> device buffers + BVH) and the launch of the render
+// kernel for a frame or for a batch of caller-supplied rays.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,7 +1,6 @@
 // Device-side view of an uploaded scene and of a render in flight.
 // Shared by the HIP kernels (kernels.hip) and the host code that fills it
-// (mirt_api.cpp).  Everything here is plain data passed by value as a kernel
-// argument; pointers are device pointers.
+// (mirt_api.cpp).  Everything here is plain data; pointers are device pointers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,7 +14,7 @@ namespace mirt {
 //   bit 31 clear: index of an inner node
 //   bit 31 set:   a leaf = (count - 1) in bits 28..30, index of its first primitive record in bits 0..27
 //                 (a leaf's primitives are consecutive records)
-// Hit references (what extend hands to shade, what trace resolves to ids):
+// Hit references (what the walk hands to shading, what a trace resolves to ids):
 //   bit 31 set, primitive kind (TAG_*) in bits 28..30, record index in bits 0..27;
 //   TAG_MEDIUM + medium number for a constant medium; REF_NONE for a miss.
 constexpr uint32_t REF_LEAF = 0x80000000u;
@@ -35,7 +34,6 @@ __host__ __device__ inline uint32_t make_material_word(uint32_t kind, uint32_t i
 // Traversal stack entries per lane (kept in LDS).  The host builder never
 // produces a tree taller than STACK_DEPTH - 2.
 constexpr int STACK_DEPTH = 32;
-constexpr int BLOCK_THREADS = 256;      // trace
 constexpr int RENDER_THREADS = 1024;    // render: one block per region, a CU's worth of waves
 constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
@@ -52,7 +50,8 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 //   qb =                         | moving sphere (c1, time0)  | rect (k, bits(axis),-,-) | box (max, -)
 //   qc = bits(chain << 2 | kind), bits(order = tie-break rank), bits(material word), moving sphere: time1
 //   qd = bits(flags), -, -, -
-// Traversal needs qa..qc only; when the scene fits, extend keeps those 48 bytes per primitive in LDS.
+// Traversal and shading need qa..qc only; when the scene fits, the render kernel keeps those 48 bytes per
+// primitive in LDS.
 // prim_ids: uint2 (type_index, object_index) per record (only read when ids are reported).
 constexpr uint32_t PRIM_QUADS = 4;      // record stride in global memory
 constexpr uint32_t PRIM_QUADS_LDS = 3;  // record stride of the LDS copy
@@ -188,7 +187,7 @@ struct RenderConst {
 //   r0 = origin.xyz, time
 //   r1 = direction.xyz, bits(pixel = y*width + x, y up)
 //   r2 = throughput.rgb, bits(sample index << 8 | bounce)
-//   r3 = t of the closest surface, bits(hit ref), bits(side of a box hit), -     (the only part extend writes
+//   r3 = t of the closest surface, bits(hit ref), bits(side of a box hit), -     (the only part the walk writes
 //        for a surviving path)
 // Material queue q of region s holds slot numbers (within the region) at queues[(s * N_QUEUES + q) * region_cap ...].
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
