@@ -1,0 +1,58 @@
+"""Progressive accumulation and checkpoint/resume (raytracing_amd/progressive.py)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import raytracing_amd as R
+from raytracing_amd.progressive import Progressive, encode_rgb24
+
+
+def test_host_encoder_matches_the_oracle_encoder():
+    """renderer.rs:241-252 in numpy against the oracle's restatement, special values included."""
+    rng = np.random.default_rng(3)
+    sums = (rng.random((40, 50, 3), dtype=np.float32) * 40).astype(np.float32)
+    sums.flat[:8] = [0.0, -1.0, np.nan, np.inf, -np.inf, 1e-30, 16.0, 15.99]
+    for spp in (1, 16, 37):
+        assert np.array_equal(encode_rgb24(sums, spp), O.encode(sums, spp))
+
+
+class FakeScene:
+    """Stands in for the GPU: sample s of every pixel contributes s + 1."""
+    depth = 5
+
+    def render(self, w, h, spp, depth=None, aspect=0.0, seed=7, first_sample=0):
+        s = np.zeros((h, w, 3), np.float32)
+        for k in range(first_sample, first_sample + spp):
+            s += k + 1
+        return None, s, {}
+
+
+def test_checkpoint_round_trip_and_resume(tmp_path):
+    acc = Progressive(FakeScene(), 6, 4, seed=11, aspect=1.5).render(5, pass_size=2)
+    assert acc.samples == 5 and np.all(acc.sums == 15)
+    p = tmp_path / "frame.ckpt"
+    acc.save(p)
+    back = Progressive.load(FakeScene(), p)
+    assert (back.width, back.height, back.seed, back.samples, back.aspect) == (6, 4, 11, 5, 1.5)
+    assert np.array_equal(back.sums, acc.sums)
+    back.render(3)
+    assert back.samples == 8 and np.all(back.sums == 36)
+    p.write_bytes(p.read_bytes()[:-4])
+    with pytest.raises(ValueError):
+        Progressive.load(FakeScene(), p)
+
+
+@pytest.mark.gpu
+def test_resumed_render_equals_uninterrupted_one(tmp_path):
+    g = R.ExampleScene("cornel_box")
+    w, h = 160, 160
+    straight = Progressive(g, w, h, seed=5, aspect=1.0).render(24)
+    first = Progressive(g, w, h, seed=5, aspect=1.0).render(10, pass_size=4)
+    first.save(tmp_path / "a.ckpt")
+    second = Progressive.load(g, tmp_path / "a.ckpt").render(14, pass_size=5)
+    assert second.samples == 24
+    ok = np.isfinite(straight.sums) & np.isfinite(second.sums)
+    assert ok.mean() > 0.995
+    assert np.allclose(second.sums[ok], straight.sums[ok], rtol=1e-4, atol=1e-5)
+    diff = np.abs(second.image().astype(int) - straight.image().astype(int))
+    assert diff[ok].max() <= 1
