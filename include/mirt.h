@@ -199,6 +199,14 @@ enum {
 
 /* ---- the lowered scene ------------------------------------------------------ */
 
+/* BVH builders (mirt_scene_desc.build_flags).  The reference builds on the host, single-threaded
+ * (src/bvh.rs:24-81).  The closest hit does not depend on the choice, only the time to build and to find it. */
+enum {
+  MIRT_BUILD_AUTO = 0,         /* host below 2^18 primitives, device from there up */
+  MIRT_BUILD_HOST_SAH = 1,     /* binned surface-area build on the host: best tree, seconds for millions */
+  MIRT_BUILD_DEVICE_MORTON = 2 /* Morton-order build on the GPU: milliseconds, looser tree */
+};
+
 typedef struct mirt_scene_desc {
   const mirt_sphere* spheres;
   uint32_t n_spheres;
@@ -236,6 +244,7 @@ typedef struct mirt_scene_desc {
    * are bounded over this interval).  Cameras and rays outside it are
    * rejected. */
   float time0, time1;
+  uint32_t build_flags; /* MIRT_BUILD_*: who builds the BVH; 0 leaves it to the library */
 } mirt_scene_desc;
 
 /* The ten fields of camera.rs:4-15. */

@@ -109,7 +109,7 @@ class SceneDesc(C.Structure):
                 ("lights_mode", C.c_uint32),
                 ("lights", C.POINTER(Light)), ("n_lights", C.c_uint32),
                 ("light_groups", C.POINTER(LightGroup)), ("n_light_groups", C.c_uint32),
-                ("time0", C.c_float), ("time1", C.c_float)]
+                ("time0", C.c_float), ("time1", C.c_float), ("build_flags", C.c_uint32)]
 
 
 class Camera(C.Structure):

@@ -16,6 +16,7 @@
 
 #include "../../include/mirt.h"
 #include "bvh_build.h"
+#include "bvh_gpu.h"
 #include "scene_device.h"
 
 using namespace mirt;
@@ -368,10 +369,42 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     const long v = std::strtol(e, nullptr, 10);
     if (v >= 1 && v <= 8) leaf_max = (uint32_t)v;
   }
-  BuiltBvh bvh = build_bvh(build, STACK_DEPTH - 2, leaf_max);
-  if (bvh.height > (uint32_t)STACK_DEPTH - 1) return fail(ctx, MIRT_ERR_UNSUPPORTED, "BVH taller than the traversal stack");
-  s.bvh_height = bvh.height;
-  MIRT_HIP(ctx, upload(s.nodes, bvh.nodes));
+  // Which builder: the host's surface-area build gives the faster tree, the device's Morton-order build takes
+  // milliseconds where the host takes seconds.  Left to the library, the device builds from 2^18 primitives up.
+  uint32_t builder = d.build_flags & (MIRT_BUILD_HOST_SAH | MIRT_BUILD_DEVICE_MORTON);
+  if (const char* e = std::getenv("MIRT_BVH_BUILDER")) {  // overrides the description: "host" or "device"
+    if (!std::strcmp(e, "host")) builder = MIRT_BUILD_HOST_SAH;
+    else if (!std::strcmp(e, "device")) builder = MIRT_BUILD_DEVICE_MORTON;
+  }
+  if (builder != MIRT_BUILD_HOST_SAH && builder != MIRT_BUILD_DEVICE_MORTON)
+    builder = build.size() >= (1u << 18) ? MIRT_BUILD_DEVICE_MORTON : MIRT_BUILD_HOST_SAH;
+  const auto t_build = std::chrono::steady_clock::now();
+  uint32_t root_ref = REF_NONE, n_nodes = 0;
+  if (builder == MIRT_BUILD_DEVICE_MORTON) {
+    GpuBvh g;
+    MIRT_HIP(ctx, build_bvh_gpu(build, std::min(leaf_max, 2u), STACK_DEPTH - 2, ctx->stream, g));
+    s.nodes.release();
+    s.nodes.ptr = g.nodes;
+    s.nodes.bytes = std::max<size_t>(16, (size_t)g.n_nodes * 64);
+    std::vector<BuildPrim> sorted(build.size());
+    for (size_t k = 0; k < build.size(); ++k) sorted[k] = build[g.order[k]];
+    build.swap(sorted);
+    root_ref = g.root_ref;
+    n_nodes = g.n_nodes;
+    s.bvh_height = g.height;
+  } else {
+    BuiltBvh bvh = build_bvh(build, STACK_DEPTH - 2, leaf_max);
+    MIRT_HIP(ctx, upload(s.nodes, bvh.nodes));
+    root_ref = bvh.root_ref;
+    n_nodes = (uint32_t)bvh.nodes.size();
+    s.bvh_height = bvh.height;
+  }
+  if (s.bvh_height > (uint32_t)STACK_DEPTH - 2) return fail(ctx, MIRT_ERR_UNSUPPORTED, "BVH taller than the traversal stack");
+  if (std::getenv("MIRT_VERBOSE"))
+    std::fprintf(stderr, "mirt: %s BVH build of %zu primitives: %.1f ms, %u nodes, height %u\n",
+                 builder == MIRT_BUILD_DEVICE_MORTON ? "device (Morton order)" : "host (surface-area)", build.size(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count(), n_nodes,
+                 s.bvh_height);
   // records in tree order, boundary-only records behind them
   std::vector<float4> rec(n_all * PRIM_QUADS);
   std::vector<uint2> ids(n_all);
@@ -476,9 +509,9 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
 
   DeviceScene& v = s.view;
   v.nodes = s.nodes.as<float4>();
-  v.root_ref = bvh.root_ref;
-  v.n_nodes = (uint32_t)bvh.nodes.size();
-  v.bvh_height = bvh.height;
+  v.root_ref = root_ref;
+  v.n_nodes = n_nodes;
+  v.bvh_height = s.bvh_height;
   v.n_chains = d.n_chains;
   v.prims = s.prims.as<float4>();
   v.prim_ids = s.prim_ids.as<uint2>();

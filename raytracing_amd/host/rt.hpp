@@ -722,16 +722,24 @@ class DeviceScene {
   template <class H, class LT>
   Status build(const H& hittable, const LT* lights, float time0, float time1, int device = 0) {
     reset();
+    const auto t0 = std::chrono::steady_clock::now();
     Lowerer L;
     lower_root(hittable, L);
     if (lights) lights->lower_lights_argument(L);
     if (!L.error.empty()) return Status::err("cannot lower scene: " + L.error);
     const mirt_scene_desc desc = make_desc(L, time0, time1);
+    const auto t1 = std::chrono::steady_clock::now();
     if (mirt_context_create(device, &ctx_) != MIRT_OK) return Status::err(mirt_last_error(nullptr));
+    const auto t2 = std::chrono::steady_clock::now();
     if (mirt_scene_upload(ctx_, &desc, &scene_) != MIRT_OK) {
       const std::string e = mirt_last_error(ctx_);
       reset();
       return Status::err(e);
+    }
+    if (std::getenv("MIRT_VERBOSE")) {
+      auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      std::fprintf(stderr, "rt: lowering %.0f ms, context %.0f ms, scene upload (incl. BVH) %.0f ms\n", ms(t0, t1),
+                   ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
     }
     n_media_ = (uint32_t)L.media.size();
     n_prims_ = L.spheres.size() + L.moving_spheres.size() + L.rects.size() + L.boxes.size();

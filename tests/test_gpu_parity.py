@@ -209,3 +209,29 @@ def test_depth_limits_and_background(scenes):
     orgb, osums, _ = o.render(32, 18, 4, depth=1, seed=5)
     assert np.allclose(sums, osums, rtol=1e-5, atol=1e-6)
     assert np.allclose(sums[0] / 4, 0.8, atol=1e-6)     # sky row: background (renderer.rs:187-189)
+
+
+@pytest.mark.parametrize("name,lo,hi", [("spheres_bvh", [-12, 0.0, -12], [12, 3, 12]),
+                                        ("cornel_box", [0, 0, -800], [555, 555, 555]),
+                                        ("synthetic_bvh:40", [-42, 0.0, -42], [42, 3, 42])])
+def test_device_built_tree_finds_the_same_hits(name, lo, hi, monkeypatch):
+    """The closest hit does not depend on the tree: with the BVH built on the GPU (Morton order, balanced levels)
+    ids and t are still the oracle's, bit for bit, and the same-seed image is the one the host-built tree gives."""
+    monkeypatch.setenv("MIRT_BVH_BUILDER", "device")
+    g, o = R.ExampleScene(name), O.Scene(name)
+    monkeypatch.delenv("MIRT_BVH_BUILDER")
+    try:
+        cam, _ = g.camera()
+        rays = np.concatenate([R.camera_rays(cam, 120, 68), random_rays(20000, lo, hi, 31)])
+        assert_same_hits(g, o, rays)
+        aspect = 1.0 if name == "cornel_box" else 0.0
+        rgb, sums, _ = g.render(96, 96, 4, aspect=aspect, seed=9)
+        h = R.ExampleScene(name)          # host-built tree
+        rgb2, sums2, _ = h.render(96, 96, 4, aspect=aspect, seed=9)
+        h.close()
+        ok = np.isfinite(sums) & np.isfinite(sums2)
+        assert ok.mean() > 0.995
+        assert np.allclose(sums[ok], sums2[ok], rtol=1e-4, atol=1e-5)
+    finally:
+        g.close()
+        o.close()
