@@ -28,7 +28,7 @@ class Ctx:
         return self.L.mirt_last_error(self.ctx).decode()
 
     def upload(self, spheres=(), rects=(), boxes=(), moving=(), materials=None, textures=None, chains=None,
-               chain_ops=(), time=(0.0, 1.0), expect=0):
+               chain_ops=(), media=(), time=(0.0, 1.0), expect=0):
         keep = []
 
         def arr(T, items):
@@ -47,6 +47,7 @@ class Ctx:
         textures = textures if textures is not None else [R.Texture(0, (C.c_float * 3)(0.5, 0.5, 0.5), 0, 0, 0.0, 0)]
         d.materials, d.n_materials = arr(R.Material, materials), len(materials)
         d.textures, d.n_textures = arr(R.Texture, textures), len(textures)
+        d.media, d.n_media = arr(R.Medium, media), len(media)
         d.time0, d.time1 = time
         scene = C.c_void_p()
         rc = self.L.mirt_scene_upload(self.ctx, C.byref(d), C.byref(scene))
@@ -199,3 +200,34 @@ def test_render_of_one_emissive_sphere(ctx):
     rgb, sums, st = ctx.render(scene, 8, 8, 5)
     assert np.allclose(sums, 10.0)
     assert np.all(rgb == 255)
+
+
+def test_constant_medium_inside_a_box_boundary(ctx):
+    """ConstantMedium over a Box3d boundary, the smoke box of a Cornell scene (transforms.rs:134-180).  With a
+    density so high that -1/density is -0 the free flight is 0 whatever the draw, so the ray scatters exactly
+    where it enters the boundary; the boundary itself is not a surface.  A Translate around the medium moves it."""
+    dense = -0.0
+    box = R.Box(hdr(0, 0, 0, flags=1), (C.c_float * 3)(-1, -1, -6), (C.c_float * 3)(1, 1, -4))     # boundary only
+    far = sphere((0, 0, -20), 2.0, order=1, ti=1, oi=0)
+    mats = [R.Material(0, 0, 0.0), R.Material(4, 0, 0.0)]                                             # lambertian, isotropic
+    smoke = R.Medium(3, 0, dense, 1, 0, 2, 7, 3)                                                        # box 0, WorldIndex (7, 3)
+    scene = ctx.upload(spheres=[far], boxes=[box], materials=mats, media=[smoke])
+    ti, oi, t = ctx.trace(scene, [[0, 0, 0, 0, 0, -1, 0],        # enters the box at z = -4
+                                  [0, 0, -5, 0, 0, -1, 0],       # starts inside: scatters at once (t_min)
+                                  [3, 0, 0, 0, 0, -1, 0],        # passes beside the box: nothing on its way
+                                  [0, 0, -30, 0, 0, 1, 0]])      # from behind: the sphere is hit first, t = 8
+    assert list(ti) == [7, 7, 0xFFFFFFFF, 1] and list(oi[:2]) == [3, 3]
+    assert t[0] == 4.0 and t[1] == F(0.001) and t[3] == 8.0
+    # the same smoke box wrapped in Translate((0, 0, -2)): the boundary's chain and the medium's chain
+    ops = [R.ChainOp(0, (C.c_float * 3)(0, 0, -2))]
+    chains = [R.Chain(0, 0), R.Chain(0, 1)]
+    box2 = R.Box(hdr(0, 0, 0, chain=1, flags=1), (C.c_float * 3)(-1, -1, -6), (C.c_float * 3)(1, 1, -4))
+    smoke2 = R.Medium(3, 0, dense, 1, 1, 2, 7, 3)
+    scene2 = ctx.upload(spheres=[far], boxes=[box2], materials=mats, media=[smoke2], chains=chains, chain_ops=ops)
+    ti, _, t = ctx.trace(scene2, [[0, 0, 0, 0, 0, -1, 0]])
+    assert ti[0] == 7 and t[0] == 6.0
+    # rendered: every camera ray that meets the smoke ends there (isotropic: no scatter, no emission) -> black;
+    # the others see the background or the grey sphere
+    rgb, sums, _ = ctx.render(scene, 32, 32, 4, bg=(1.0, 1.0, 1.0))
+    assert np.all(sums[14:18, 14:18] == 0.0)
+    assert np.all(sums[0, :] > 0.0)
