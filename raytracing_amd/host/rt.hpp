@@ -24,6 +24,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <thread>
+#include <unordered_map>
 #include <memory>
 #include <string>
 #include <typeindex>
@@ -134,20 +136,39 @@ struct Lowerer {
   int32_t last_boundary_tag = -1;
   uint32_t last_boundary_index = 0;
   uint32_t boundary_prims = 0;
-  std::map<std::vector<uint32_t>, uint32_t> chain_cache;
-  std::map<std::vector<uint32_t>, uint32_t> material_cache, texture_cache;
+  // Equal chains / materials / textures are stored once.  Keys are the records' bytes (all of them are
+  // zero-initialised before they are filled in, so padding compares equal); a scene of millions of
+  // differently coloured spheres makes millions of entries, hence hashing.
+  template <class T>
+  struct BytesHash {
+    size_t operator()(const T& t) const {
+      const unsigned char* p = reinterpret_cast<const unsigned char*>(&t);
+      uint64_t h = 1469598103934665603ull;  // FNV-1a
+      for (size_t i = 0; i < sizeof(T); ++i) { h ^= p[i]; h *= 1099511628211ull; }
+      return (size_t)h;
+    }
+  };
+  template <class T>
+  struct BytesEqual {
+    bool operator()(const T& a, const T& b) const { return std::memcmp(&a, &b, sizeof(T)) == 0; }
+  };
+  struct ChainKey {
+    uint32_t n;
+    mirt_chain_op ops[MIRT_MAX_CHAIN_OPS];
+  };
+  std::unordered_map<ChainKey, uint32_t, BytesHash<ChainKey>, BytesEqual<ChainKey>> chain_cache;
+  std::unordered_map<mirt_material, uint32_t, BytesHash<mirt_material>, BytesEqual<mirt_material>> material_cache;
+  std::unordered_map<mirt_texture, uint32_t, BytesHash<mirt_texture>, BytesEqual<mirt_texture>> texture_cache;
 
   void unsupported(const std::string& what) { if (error.empty()) error = what; }
 
-  static std::vector<uint32_t> bits(const void* p, size_t n) {
-    std::vector<uint32_t> v(n / 4);
-    std::memcpy(v.data(), p, n);
-    return v;
-  }
   uint32_t current_chain() {
     if (wrappers.empty()) return 0;
     if (wrappers.size() > MIRT_MAX_CHAIN_OPS) { unsupported("more than MIRT_MAX_CHAIN_OPS nested wrappers"); return 0; }
-    const auto key = bits(wrappers.data(), wrappers.size() * sizeof(mirt_chain_op));
+    ChainKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.n = (uint32_t)wrappers.size();
+    std::memcpy(key.ops, wrappers.data(), wrappers.size() * sizeof(mirt_chain_op));
     auto it = chain_cache.find(key);
     if (it != chain_cache.end()) return it->second;
     mirt_chain c{(uint32_t)chain_ops.size(), (uint32_t)wrappers.size()};
@@ -156,16 +177,16 @@ struct Lowerer {
     chain_cache[key] = (uint32_t)chains.size() - 1;
     return (uint32_t)chains.size() - 1;
   }
-  uint32_t add_texture(const mirt_texture& t) {
-    const auto key = bits(&t, sizeof(t));
+  uint32_t add_texture(const mirt_texture& key) {
+    const mirt_texture& t = key;
     auto it = texture_cache.find(key);
     if (it != texture_cache.end()) return it->second;
     textures.push_back(t);
     texture_cache[key] = (uint32_t)textures.size() - 1;
     return (uint32_t)textures.size() - 1;
   }
-  uint32_t add_material(const mirt_material& m) {
-    const auto key = bits(&m, sizeof(m));
+  uint32_t add_material(const mirt_material& key) {
+    const mirt_material& m = key;
     auto it = material_cache.find(key);
     if (it != material_cache.end()) return it->second;
     materials.push_back(m);
@@ -602,7 +623,8 @@ struct BVH final : Hittable {
     BVH b;
     b.world = std::move(w);
     auto volumes = b.world.volumes();
-    if (!volumes.empty()) b.root_box = order_leaves(b.leaf_order, volumes.data(), volumes.size(), 0);
+    b.leaf_order.resize(volumes.size());
+    if (!volumes.empty()) b.root_box = order_leaves(b.leaf_order.data(), volumes.data(), volumes.size(), 0, 0);
     (void)time0; (void)time1;  // accepted and ignored, as in the reference
     return b;
   }
@@ -611,20 +633,39 @@ struct BVH final : Hittable {
   }
   // The recursion of create_node (bvh.rs:31-81) reduced to what decides a
   // tie between equal hit distances: the left-to-right order of the leaves.
-  static AABB order_leaves(std::vector<WorldIndex>& out, std::pair<WorldIndex, AABB>* v, size_t n, int axis) {
+  // `out` receives the n leaves of this subtree.  The two halves are independent, so for big inputs the first
+  // few levels hand one half to another thread (the reference is single-threaded; the order is the same).
+  static AABB order_leaves(WorldIndex* out, std::pair<WorldIndex, AABB>* v, size_t n, int axis, int depth) {
     const int cmp_axis = axis;
     axis = (axis + 1) % 3;
-    if (n == 1) { out.push_back(v[0].first); return v[0].second; }
+    if (n == 1) { out[0] = v[0].first; return v[0].second; }
     if (n == 2) {
       const bool swap = key(v[0], cmp_axis) > key(v[1], cmp_axis);  // Less/Equal keep, Greater swaps
-      out.push_back(v[swap ? 1 : 0].first);
-      out.push_back(v[swap ? 0 : 1].first);
+      out[0] = v[swap ? 1 : 0].first;
+      out[1] = v[swap ? 0 : 1].first;
       return AABB::surrounding_box(v[0].second, v[1].second);
     }
-    std::stable_sort(v, v + n, [cmp_axis](const auto& a, const auto& b) { return key(a, cmp_axis) < key(b, cmp_axis); });
+    if (n <= 24) {  // a stable insertion sort: same order as the library's stable sort, no scratch allocation
+      for (size_t i = 1; i < n; ++i) {
+        const auto item = v[i];
+        const float k = key(item, cmp_axis);
+        size_t j = i;
+        for (; j > 0 && key(v[j - 1], cmp_axis) > k; --j) v[j] = v[j - 1];
+        v[j] = item;
+      }
+    } else {
+      std::stable_sort(v, v + n, [cmp_axis](const auto& a, const auto& b) { return key(a, cmp_axis) < key(b, cmp_axis); });
+    }
     const size_t half = n / 2;
-    const AABB l = order_leaves(out, v, half, axis);
-    const AABB r = order_leaves(out, v + half, n - half, axis);
+    AABB l, r;
+    if (depth < 4 && n >= (size_t)1 << 16) {
+      std::thread other([&] { r = order_leaves(out + half, v + half, n - half, axis, depth + 1); });
+      l = order_leaves(out, v, half, axis, depth + 1);
+      other.join();
+    } else {
+      l = order_leaves(out, v, half, axis, depth + 1);
+      r = order_leaves(out + half, v + half, n - half, axis, depth + 1);
+    }
     return AABB::surrounding_box(l, r);
   }
   AABB bounding_box() const override { return root_box; }
