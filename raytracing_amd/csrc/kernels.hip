@@ -881,7 +881,8 @@ __device__ __forceinline__ ConstArgs pinned(const RenderArgs* p) {
 }
 
 // Dynamic shared memory of the render kernel: [RenderShared][nodes][48-byte primitive records][chain ops]
-// [chains][stack] when the scene is staged (LDS_SCENE), else [RenderShared][stack].
+// [chains][materials][textures][stack] when the scene is staged (LDS_SCENE; materials and textures only if
+// args.lds_shading says they fit as well), else [RenderShared][stack].
 template <bool LDS_SCENE>
 struct RenderLds {
   using Slot = typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type;
@@ -889,6 +890,8 @@ struct RenderLds {
   float4* prims;
   float4* ops;
   float4* chains;  // two quads per chain
+  float4* materials;  // one quad per material (DMaterial)
+  float4* textures;   // two quads per texture (DTexture)
   Slot* stack;  // this thread's column; rows are RENDER_THREADS entries apart
   __device__ __forceinline__ RenderLds(float4* smem, ConstArgs A) {
     float4* after = smem + sizeof(RenderShared) / 16;
@@ -896,7 +899,10 @@ struct RenderLds {
     prims = nodes + (LDS_SCENE ? A->sc.n_nodes * 4u : 0u);
     ops = prims + (LDS_SCENE ? A->sc.n_prims * PRIM_QUADS_LDS : 0u);
     chains = ops + (LDS_SCENE ? A->sc.n_chain_ops : 0u);
-    stack = reinterpret_cast<Slot*>(chains + (LDS_SCENE ? A->sc.n_chains * 2u : 0u)) + threadIdx.x;
+    const bool shading = LDS_SCENE && A->lds_shading != 0;
+    materials = chains + (LDS_SCENE ? A->sc.n_chains * 2u : 0u);
+    textures = materials + (shading ? A->sc.n_materials : 0u);
+    stack = reinterpret_cast<Slot*>(textures + (shading ? A->sc.n_textures * 2u : 0u)) + threadIdx.x;
   }
   // the tables the walk and the shading read the scene's geometry from
   __device__ __forceinline__ SceneTables tables(ConstArgs A) const {
@@ -1094,7 +1100,11 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
   const SceneTables tb = lds.tables(A);
   const uint32_t region = blockIdx.x;
   const uint32_t lane = lane_id();
-  const ShadeTables sc = MIRT_SHADE_TABLES(A->sc);
+  ShadeTables sc = MIRT_SHADE_TABLES(A->sc);
+  if (LDS_SCENE && A->lds_shading != 0) {  // the block's own copies
+    sc.materials = reinterpret_cast<const DMaterial*>(lds.materials);
+    sc.textures = reinterpret_cast<const DTexture*>(lds.textures);
+  }
   const SceneTables gt = MIRT_GLOBAL_TABLES(A->sc);
   const uint32_t n_media = A->sc.n_media;
   struct { uint32_t width, height, max_depth, key0, key1; float background[3]; FastDiv by_width; }
@@ -1327,6 +1337,13 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
         lds.prims[k] = prims[(k / PRIM_QUADS_LDS) * PRIM_QUADS + (k % PRIM_QUADS_LDS)];
       for (uint32_t k = threadIdx.x; k < n_chain_ops; k += THREADS) lds.ops[k] = chain_ops[k];
       for (uint32_t k = threadIdx.x; k < n_chains * 2u; k += THREADS) lds.chains[k] = chains[k];
+      if (A->lds_shading != 0) {
+        const float4* materials = reinterpret_cast<const float4*>(A->sc.materials);
+        const float4* textures = reinterpret_cast<const float4*>(A->sc.textures);
+        const uint32_t n_materials = A->sc.n_materials, n_texture_quads = A->sc.n_textures * 2u;
+        for (uint32_t k = threadIdx.x; k < n_materials; k += THREADS) lds.materials[k] = materials[k];
+        for (uint32_t k = threadIdx.x; k < n_texture_quads; k += THREADS) lds.textures[k] = textures[k];
+      }
     }
   }
 
@@ -1441,6 +1458,11 @@ RenderConfig plan_render(const DeviceScene& sc) {
     cfg.lds_scene = true;
     cfg.stack_depth = depth;
     cfg.lds_bytes = lds_total;
+    const size_t shading_bytes = (size_t)sc.n_materials * sizeof(DMaterial) + (size_t)sc.n_textures * sizeof(DTexture);
+    if (lds_total + shading_bytes <= LDS_BYTES_PER_CU && !std::getenv("MIRT_NO_LDS_SHADING")) {
+      cfg.lds_shading = true;
+      cfg.lds_bytes += shading_bytes;
+    }
   } else {
     cfg.lds_scene = false;
     cfg.stack_depth = STACK_DEPTH;

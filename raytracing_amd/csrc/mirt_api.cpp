@@ -535,6 +535,8 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   }
   MIRT_HIP(ctx, upload(s.media, media));
   v.media = s.media.as<DMedium>();
+  v.n_materials = d.n_materials;
+  v.n_textures = d.n_textures;
   v.materials = s.materials.as<DMaterial>();
   v.textures = s.textures.as<DTexture>();
   v.perlin_vec = s.perlin_vec.as<float4>();
@@ -619,6 +621,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.rgb_sum = job.rgb_sum;
   args.refill_min = cfg.refill_min;
   args.node_min = cfg.node_min;
+  args.lds_shading = cfg.lds_shading ? 1u : 0u;
   args.rays = job.rays;
   args.hit_type = job.hit_type;
   args.hit_object = job.hit_object;

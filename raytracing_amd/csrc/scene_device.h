@@ -114,6 +114,7 @@ struct DeviceScene {
   uint32_t n_media;
   const DMedium* media;
 
+  uint32_t n_materials, n_textures;
   const DMaterial* materials;
   const DTexture* textures;
   const float4* perlin_vec;     // 256 per table (xyz, -)
@@ -203,6 +204,7 @@ struct RenderConfig {
   int grid;
   int stack_depth;
   size_t lds_bytes;
+  bool lds_shading;     // materials and textures fit in LDS too
   uint32_t refill_min;  // a wave hands in finished rays and fetches new ones once this many lanes have none
   uint32_t node_min;    // a wave keeps stepping down the tree while this many of its lanes hold an inner node
 };
@@ -218,6 +220,7 @@ struct RenderArgs {
   WorkCounters* work;
   float* rgb_sum;
   uint32_t refill_min, node_min;
+  uint32_t lds_shading;  // materials and textures are staged in LDS behind the wrapper chains
   // Tracing caller-supplied rays instead of rendering (rays != nullptr): rc.total_paths rays come from `rays`,
   // each is walked once, and what ray g hit goes to hit_type[g], hit_object[g], hit_t[g].
   const mirt_ray* rays;
