@@ -861,7 +861,9 @@ struct RenderShared {
   uint32_t queue_n[N_QUEUES];           // entries in the region's material queues
   uint32_t n_next;                      // survivors written to the other buffer so far
   uint32_t shade_next;                  // next batch of 64 queue entries to hand out to a shading wave
-  uint32_t pad[2];
+  uint32_t late_next;                   // the same for the second shading pass
+  uint32_t pad;
+  uint32_t late_n[N_QUEUES];            // entries appended to each queue for the second shading pass
   MediumEntry media[MIRT_MAX_MEDIA];
 };
 static_assert(sizeof(RenderShared) % 16 == 0, "keeps the node array 16-byte aligned");
@@ -1112,25 +1114,32 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
          {A->rc.background[0], A->rc.background[1], A->rc.background[2]},
          {A->rc.by_width.m, A->rc.by_width.sh1, A->rc.by_width.sh2}};
   const uint32_t cap = A->rc.region_cap;
-  const float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
   float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
-  const uint32_t* const region_queues = A->queues + (size_t)region * N_QUEUES * cap;
+  uint32_t* const region_queues = A->queues + (size_t)region * N_QUEUES * cap;
   float* const rgb_sum = A->rgb_sum;
-  // The four queues are cut into batches of 64 entries, numbered queue after queue; a wave takes the next
-  // batch whenever it has finished one, so no wave is left with the expensive ones.
-  const uint32_t n0 = sh.queue_n[0], n1 = sh.queue_n[1], n2 = sh.queue_n[2], n3 = sh.queue_n[3];
-  const uint32_t b1 = (n0 + 63u) >> 6, b2 = b1 + ((n1 + 63u) >> 6), b3 = b2 + ((n2 + 63u) >> 6);
-  const uint32_t n_batches = b3 + ((n3 + 63u) >> 6);
-  {
+  // The walk queued every ray under the material of the surface it found.  A constant medium in front of that
+  // surface changes the material, so shading takes two passes: the first gives the media their chance, shades
+  // what stays in its queue and appends the rest (written back with the medium hit) to the queue of the
+  // medium's material; the second shades those.  Every wave then runs one material's code with full lanes.
+  for (uint32_t pass = 0; pass < 2u; ++pass) {
+    // The entries of the four queues are cut into batches of 64, numbered queue after queue; a wave takes the
+    // next batch whenever it has finished one, so no wave is left with the expensive ones.
+    const uint32_t o0 = pass == 0 ? 0u : sh.queue_n[0], o1 = pass == 0 ? 0u : sh.queue_n[1];
+    const uint32_t o2 = pass == 0 ? 0u : sh.queue_n[2], o3 = pass == 0 ? 0u : sh.queue_n[3];
+    const uint32_t n0 = pass == 0 ? sh.queue_n[0] : sh.late_n[0], n1 = pass == 0 ? sh.queue_n[1] : sh.late_n[1];
+    const uint32_t n2 = pass == 0 ? sh.queue_n[2] : sh.late_n[2], n3 = pass == 0 ? sh.queue_n[3] : sh.late_n[3];
+    const uint32_t b1 = (n0 + 63u) >> 6, b2 = b1 + ((n1 + 63u) >> 6), b3 = b2 + ((n2 + 63u) >> 6);
+    const uint32_t n_batches = b3 + ((n3 + 63u) >> 6);
     for (;;) {
       uint32_t batch = 0;
-      if (lane == 0) batch = atomicAdd(&sh.shade_next, 1u);
+      if (lane == 0) batch = atomicAdd(pass == 0 ? &sh.shade_next : &sh.late_next, 1u);
       batch = uniform(batch);
       if (batch >= n_batches) break;
       const uint32_t q = batch < b1 ? 0u : (batch < b2 ? 1u : (batch < b3 ? 2u : 3u));
       const uint32_t n_q = q == 0 ? n0 : (q == 1 ? n1 : (q == 2 ? n2 : n3));
       const uint32_t e0 = (batch - (q == 0 ? 0u : (q == 1 ? b1 : (q == 2 ? b2 : b3)))) << 6;
-      const uint32_t* entries = region_queues + (size_t)q * cap;
+      const uint32_t* entries = region_queues + (size_t)q * cap + (q == 0 ? o0 : (q == 1 ? o1 : (q == 2 ? o2 : o3)));
       const uint32_t e = e0 + lane;
       bool alive = false;
       Ray nr;
@@ -1147,14 +1156,27 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
         bounce = __float_as_uint(r2.w) & 255u;
         float t = r3.x;
         uint32_t ref = __float_as_uint(r3.y);
-        if (n_media != 0) {  // the walk found the closest surface; the media in front of it get their chance now
+        bool deferred = false;
+        if (n_media != 0 && pass == 0) {  // the walk found the closest surface; the media in front of it get their chance now
           uint32_t material = 0;
+          const uint32_t surface = ref;
           Rng mrng = rng_begin(pixel, sample, bounce, STAGE_MEDIA, rc.key0, rc.key1);
           closest_media(n_media, tb, gt, sh.media, r, kTMin, mrng, ref, t, material);
+          if (ref != surface) {
+            const uint32_t to_q = (uint32_t)queue_of(material);
+            if (to_q != q) {  // another material's code: goes to the end of that queue, for the second pass
+              deferred = true;
+              cur[4 * i + 3] = make_float4(t, __uint_as_float(ref), r3.z, r3.w);
+              const uint32_t at = sh.queue_n[to_q] + atomicAdd(&sh.late_n[to_q], 1u);
+              region_queues[(size_t)to_q * cap + at] = (uint32_t)i;
+            }
+          }
         }
 
         V3 term = v3(0.0f, 0.0f, 0.0f);  // radiance that ends the path
-        if (ref == REF_NONE) {
+        if (deferred) {
+          beta = v3(0.0f, 0.0f, 0.0f);  // nothing to add to the image from here
+        } else if (ref == REF_NONE) {
           term = v3(rc.background[0], rc.background[1], rc.background[2]);  // renderer.rs:187-189
         } else {
           const Hit h = hit_record<PSTRIDE>(tb, sh.media, ref, r, t, __float_as_uint(r3.z));
@@ -1230,6 +1252,8 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
         next[4 * to + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
       }
     }
+    if (n_media == 0 || pass == 1u) break;
+    __syncthreads();  // the appended entries and their records are visible to the whole block
   }
 }
 
@@ -1375,6 +1399,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       sh.queue_n[0] = 0; sh.queue_n[1] = 0; sh.queue_n[2] = 0; sh.queue_n[3] = 0;
       sh.n_next = 0;
       sh.shade_next = 0;
+      sh.late_next = 0;
+      sh.late_n[0] = 0; sh.late_n[1] = 0; sh.late_n[2] = 0; sh.late_n[3] = 0;
     }
     __syncthreads();  // also: the staged scene is complete before the first walk
     const uint32_t n_fresh = sh.n_fresh;
