@@ -826,13 +826,7 @@ __device__ __forceinline__ uint32_t wave_reserve(bool pred, uint32_t* counter) {
   return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-__device__ __forceinline__ int queue_of(uint32_t material_word) {
-  const uint32_t kind = material_word >> 28;
-  return kind == MIRT_MAT_LAMBERTIAN ? QUEUE_LAMBERTIAN
-         : kind == MIRT_MAT_METAL    ? QUEUE_METAL
-         : kind == MIRT_MAT_DIELECTRIC ? QUEUE_DIELECTRIC
-                                       : QUEUE_TERMINATE;
-}
+__device__ __forceinline__ int queue_of(uint32_t material_word) { return (int)(material_word >> 28); }
 
 __device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv f) {
   const uint32_t t = __umulhi(f.m, n);
@@ -862,8 +856,8 @@ struct RenderShared {
   uint32_t n_next;                      // survivors written to the other buffer so far
   uint32_t shade_next;                  // next batch of 64 queue entries to hand out to a shading wave
   uint32_t late_next;                   // the same for the second shading pass
-  uint32_t pad;
   uint32_t late_n[N_QUEUES];            // entries appended to each queue for the second shading pass
+  uint32_t pad[3];
   MediumEntry media[MIRT_MAX_MEDIA];
 };
 static_assert(sizeof(RenderShared) % 16 == 0, "keeps the node array 16-byte aligned");
@@ -1026,24 +1020,26 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_
     if ((m_done != 0ull || more) && (n_out >= refill_min || n_out == 64u)) {
       if (COUNT) ts = clock64();
       // Rays that are done leave their hit in the record and their slot in the queue of the material
-      // hit.  Lane q reserves queue q's entries for the whole wave in the block's LDS counters; lane 4
-      // takes the wave's new rays off the region's list.
+      // hit.  Lane q reserves queue q's entries for the whole wave in the block's LDS counters; the lane after
+      // those takes the wave's new rays off the region's list.
       const int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(w.best_material));
-      const unsigned long long m0 = __ballot(q == 0), m1 = __ballot(q == 1), m2 = __ballot(q == 2), m3 = __ballot(q == 3);
+      unsigned long long mq = 0ull;  // the lanes handing in to the same queue as this one
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int k = 0; k < N_QUEUES; ++k) {
+        const unsigned long long m = __ballot(q == k);
+        if (q == k) mq = m;
+        if (lane == (uint32_t)k) cnt = (uint32_t)__popcll(m);
+      }
       uint32_t got = 0;
-      if (lane < 4) {
-        const unsigned long long mine = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
-        const uint32_t cnt = (uint32_t)__popcll(mine);
+      if (lane < (uint32_t)N_QUEUES) {
         if (cnt) got = atomicAdd(&sh.queue_n[lane], cnt);
-      } else if (lane == 4 && more) {
+      } else if (lane == (uint32_t)N_QUEUES && more) {
         got = atomicAdd(&sh.next_work, n_out);
       }
-      const uint32_t b0 = __builtin_amdgcn_readlane(got, 0), b1 = __builtin_amdgcn_readlane(got, 1);
-      const uint32_t b2 = __builtin_amdgcn_readlane(got, 2), b3 = __builtin_amdgcn_readlane(got, 3);
-      const uint32_t base = __builtin_amdgcn_readlane(got, 4);
+      const uint32_t base = __builtin_amdgcn_readlane(got, N_QUEUES);
+      const uint32_t bq = __shfl(got, q < 0 ? 0 : q);  // every lane takes part: the reserving lanes may not be done
       if (done) {
-        const unsigned long long mq = q == 0 ? m0 : (q == 1 ? m1 : (q == 2 ? m2 : m3));
-        const uint32_t bq = q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3));
         const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
         region_queues[(size_t)q * cap + pos] = slot;
         cur[4 * (size_t)slot + 3] =
@@ -1125,21 +1121,26 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
   for (uint32_t pass = 0; pass < 2u; ++pass) {
     // The entries of the four queues are cut into batches of 64, numbered queue after queue; a wave takes the
     // next batch whenever it has finished one, so no wave is left with the expensive ones.
-    const uint32_t o0 = pass == 0 ? 0u : sh.queue_n[0], o1 = pass == 0 ? 0u : sh.queue_n[1];
-    const uint32_t o2 = pass == 0 ? 0u : sh.queue_n[2], o3 = pass == 0 ? 0u : sh.queue_n[3];
-    const uint32_t n0 = pass == 0 ? sh.queue_n[0] : sh.late_n[0], n1 = pass == 0 ? sh.queue_n[1] : sh.late_n[1];
-    const uint32_t n2 = pass == 0 ? sh.queue_n[2] : sh.late_n[2], n3 = pass == 0 ? sh.queue_n[3] : sh.late_n[3];
-    const uint32_t b1 = (n0 + 63u) >> 6, b2 = b1 + ((n1 + 63u) >> 6), b3 = b2 + ((n2 + 63u) >> 6);
-    const uint32_t n_batches = b3 + ((n3 + 63u) >> 6);
+    uint32_t first[N_QUEUES], count[N_QUEUES], last_batch[N_QUEUES];
+    uint32_t n_batches = 0;
+#pragma unroll
+    for (int k = 0; k < N_QUEUES; ++k) {
+      const uint32_t walked = uniform(sh.queue_n[k]);
+      first[k] = pass == 0 ? 0u : walked;
+      count[k] = pass == 0 ? walked : uniform(sh.late_n[k]);
+      n_batches += (count[k] + 63u) >> 6;
+      last_batch[k] = n_batches;
+    }
     for (;;) {
       uint32_t batch = 0;
       if (lane == 0) batch = atomicAdd(pass == 0 ? &sh.shade_next : &sh.late_next, 1u);
       batch = uniform(batch);
       if (batch >= n_batches) break;
-      const uint32_t q = batch < b1 ? 0u : (batch < b2 ? 1u : (batch < b3 ? 2u : 3u));
-      const uint32_t n_q = q == 0 ? n0 : (q == 1 ? n1 : (q == 2 ? n2 : n3));
-      const uint32_t e0 = (batch - (q == 0 ? 0u : (q == 1 ? b1 : (q == 2 ? b2 : b3)))) << 6;
-      const uint32_t* entries = region_queues + (size_t)q * cap + (q == 0 ? o0 : (q == 1 ? o1 : (q == 2 ? o2 : o3)));
+      uint32_t q = 0, n_q = count[0], e0 = batch << 6, from = first[0];
+#pragma unroll
+      for (int k = 1; k < N_QUEUES; ++k)
+        if (batch >= last_batch[k - 1]) { q = k; n_q = count[k]; e0 = (batch - last_batch[k - 1]) << 6; from = first[k]; }
+      const uint32_t* entries = region_queues + (size_t)q * cap + from;
       const uint32_t e = e0 + lane;
       bool alive = false;
       Ray nr;
@@ -1396,11 +1397,10 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       }
       sh.n_fresh = fresh;
       sh.next_work = 0;
-      sh.queue_n[0] = 0; sh.queue_n[1] = 0; sh.queue_n[2] = 0; sh.queue_n[3] = 0;
+      for (int q = 0; q < N_QUEUES; ++q) { sh.queue_n[q] = 0; sh.late_n[q] = 0; }
       sh.n_next = 0;
       sh.shade_next = 0;
       sh.late_next = 0;
-      sh.late_n[0] = 0; sh.late_n[1] = 0; sh.late_n[2] = 0; sh.late_n[3] = 0;
     }
     __syncthreads();  // also: the staged scene is complete before the first walk
     const uint32_t n_fresh = sh.n_fresh;

@@ -167,6 +167,18 @@ bool check_header(const mirt_scene_desc& d, const mirt_prim_header& h, std::stri
   return true;
 }
 
+// The queue hits on material `index` are shaded in (indices are validated before this is called).
+uint32_t queue_of_material(const mirt_scene_desc& d, uint32_t index) {
+  const mirt_material& m = d.materials[index];
+  switch (m.kind) {
+    case MIRT_MAT_LAMBERTIAN:
+      return d.textures[m.texture].kind == MIRT_TEX_SOLID ? QUEUE_LAMBERTIAN : QUEUE_LAMBERTIAN_TEXTURED;
+    case MIRT_MAT_METAL: return QUEUE_METAL;
+    case MIRT_MAT_DIELECTRIC: return QUEUE_DIELECTRIC;
+    default: return QUEUE_TERMINATE;
+  }
+}
+
 int validate_desc(const mirt_scene_desc& d, std::string& why) {
   if (d.n_chains == 0 || !d.chains || d.chains[0].n_ops != 0) { why = "chains[0] must be the empty chain"; return MIRT_ERR_INVALID_ARGUMENT; }
   if (d.n_chain_ops > (1u << 20)) { why = "more than 2^20 chain operations"; return MIRT_ERR_UNSUPPORTED; }
@@ -303,7 +315,7 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   auto bits = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
   auto finish = [&](Bounds& b, uint32_t tag, uint32_t g, const mirt_prim_header& h, float time1) -> bool {
     src[PRIM_QUADS * (size_t)g + 2] = make_float4(bits((h.chain << 2) | tag), bits(h.order),
-                                                  bits(make_material_word(d.materials[h.material].kind, h.material)), time1);
+                                                  bits(make_material_word(queue_of_material(d, h.material), h.material)), time1);
     src[PRIM_QUADS * (size_t)g + 3] = make_float4(bits(h.flags), 0, 0, 0);
     src_ids[g] = make_uint2(h.type_index, h.object_index);
     b.pad();
@@ -526,7 +538,7 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     DMedium& dm = media[i];
     dm.boundary_ref = make_leaf(m.boundary_tag, position[first_of_tag[m.boundary_tag] + m.boundary_index]);
     dm.neg_inv_density = m.neg_inv_density;
-    dm.material_word = make_material_word(d.materials[m.material].kind, m.material);
+    dm.material_word = make_material_word(queue_of_material(d, m.material), m.material);
     dm.chain = m.chain;
     dm.order = m.order;
     dm.type_index = m.type_index;

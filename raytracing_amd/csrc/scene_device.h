@@ -28,8 +28,8 @@ __host__ __device__ inline uint32_t make_leaf(uint32_t tag, uint32_t index) { re
 __host__ __device__ inline uint32_t ref_tag(uint32_t ref) { return (ref >> 28) & 7u; }
 __host__ __device__ inline uint32_t ref_index(uint32_t ref) { return ref & 0x0FFFFFFFu; }
 
-// material word: bits 28..31 material kind, bits 0..27 material index
-__host__ __device__ inline uint32_t make_material_word(uint32_t kind, uint32_t index) { return (kind << 28) | index; }
+// material word: bits 28..31 the queue a hit on this material is shaded in (QUEUE_*), bits 0..27 material index
+__host__ __device__ inline uint32_t make_material_word(uint32_t queue, uint32_t index) { return (queue << 28) | index; }
 
 // Traversal stack entries per lane (kept in LDS).  The host builder never
 // produces a tree taller than STACK_DEPTH - 2.
@@ -154,7 +154,10 @@ struct WorkCounters {
   unsigned long long cycles[MIRT_PHASE_COUNT];
 };
 
-constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3, N_QUEUES = 4;
+// Hits are shaded queue by queue so that a wave runs one material's code: Lambertian surfaces of one colour,
+// metal, glass, what ends the path (lights, Isotropic, misses), Lambertian surfaces with a texture to evaluate.
+constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3,
+              QUEUE_LAMBERTIAN_TEXTURED = 4, N_QUEUES = 5;
 
 // Division of a 32-bit number by a divisor fixed for the whole launch: a multiply-high and two shifts in
 // place of the long sequence a division compiles to (Granlund & Montgomery, unsigned case).
