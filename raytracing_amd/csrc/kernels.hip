@@ -959,18 +959,23 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
     Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, key0, key1);
     const float u = ((float)x + rng_next(rng)) / (float)(width - 1);
     const float v = ((float)y + rng_next(rng)) / (float)(height - 1);
-    V3 disk;
-    for (;;) {  // vec3.rs:53-60
-      const float dx = rng_range(rng, -1.0f, 1.0f);
-      const float dy = rng_range(rng, -1.0f, 1.0f);
-      disk = v3(dx, dy, 0.0f);
-      if (len2(disk) < 1.0f) break;
+    // The shutter time is drawn ahead of the lens sample (camera.rs:58,66 draws it after; the draws are
+    // independent): a pinhole camera, whose lens sample is multiplied by zero, then needs neither the
+    // rejection loop nor a second block of random numbers.
+    const float time = rng_range(rng, time0, time1);
+    V3 disk = v3(0.0f, 0.0f, 0.0f);
+    if (lens_radius != 0.0f) {
+      for (;;) {  // vec3.rs:53-60
+        const float dx = rng_range(rng, -1.0f, 1.0f);
+        const float dy = rng_range(rng, -1.0f, 1.0f);
+        disk = v3(dx, dy, 0.0f);
+        if (len2(disk) < 1.0f) break;
+      }
     }
     const V3 rd = lens_radius * disk;
     const V3 offset = cu * rd.x + cv * rd.y;
     const V3 d = llc + u * hor + v * ver - origin - offset;
     const V3 o = origin + offset;
-    const float time = rng_range(rng, time0, time1);
     cur[4 * i] = make_float4(o.x, o.y, o.z, time);
     cur[4 * i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
     cur[4 * i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
