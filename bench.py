@@ -62,8 +62,8 @@ def cpu_baseline(scene, width, height, depth):
     import oracle_lib as O
     cores = min(16, os.cpu_count() or 1)
     o = O.Scene(scene)
-    # about 2 M samples of the same framing: a quarter of the resolution per axis, 16 spp
-    w, h, spp = max(2, width // 4), max(2, height // 4), 16
+    # about 12 M samples of the same framing (10-20 s of CPU work): a quarter of the resolution per axis, 96 spp
+    w, h, spp = max(2, width // 4), max(2, height // 4), 96
     t0 = time.perf_counter()
     _, _, segments = o.render(w, h, spp, depth=depth, aspect=width / height, threads=cores)
     dt = time.perf_counter() - t0
