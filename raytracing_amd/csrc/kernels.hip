@@ -708,14 +708,18 @@ __device__ __forceinline__ V3 random_cosine_direction(Rng& rng) {  // vec3.rs:62
   const float z = sqrtf(1.0f - r2);
   const float phi = 2.0f * kPi * r1;
   const float sr = sqrtf(r2);
-  return v3(cosf(phi) * sr, sinf(phi) * sr, z);
+  float sn, cs;
+  sincosf(phi, &sn, &cs);  // one argument reduction for both
+  return v3(cs * sr, sn * sr, z);
 }
 __device__ __forceinline__ V3 random_to_sphere(Rng& rng, float radius, float dist2) {  // vec3.rs:76-88
   const float r1 = rng_next(rng), r2 = rng_next(rng);
   const float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / dist2) - 1.0f);
   const float phi = 2.0f * kPi * r1;
   const float s = sqrtf(1.0f - z * z);
-  return v3(cosf(phi) * s, sinf(phi) * s, z);
+  float sn, cs;
+  sincosf(phi, &sn, &cs);
+  return v3(cs * s, sn * s, z);
 }
 __device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) {  // vec3.rs:44-51
   for (;;) {
