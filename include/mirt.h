@@ -263,8 +263,20 @@ typedef struct mirt_camera {
 
 enum {
   MIRT_RENDER_COUNT_WORK = 1u,   /* fill mirt_stats.nodes_visited / prims_tested (slower) */
-  MIRT_RENDER_TIME_KERNELS = 2u  /* fill mirt_stats.kernel_ms / kernel_launches with HIP event times */
+  MIRT_RENDER_TIME_KERNELS = 2u, /* fill mirt_stats.kernel_ms / kernel_launches with HIP event times */
+  /* Opt-in changes to the estimator.  None of them has a counterpart in the reference: with all of them off
+   * (the default) a render is the reference's estimator, sample for sample. */
+  MIRT_RENDER_EVEN_LIGHTS = 4u,    /* a World of lights is sampled uniformly over its objects, the distribution its
+                                      pdf_value (world.rs:100-110) already assumes; World::random (world.rs:112-117)
+                                      picks a type first, which only agrees when every type has equally many */
+  MIRT_RENDER_DROP_NONFINITE = 8u, /* a sample whose radiance is NaN or infinite adds nothing, instead of turning
+                                      its pixel black (renderer.rs:241-252 encodes a NaN sum as 0) */
+  MIRT_RENDER_STRATA_SHIFT = 8,    /* bits 8..15: n > 0 stratifies the pixel jitter of renderer.rs:216-217 over
+                                      n x n cells, sample k in cell k mod n*n (whole multiples of n*n samples per
+                                      pixel cover the pixel evenly) */
+  MIRT_RENDER_STRATA_MASK = 0xFF00u
 };
+#define MIRT_RENDER_STRATA(n) (((uint32_t)(n) << MIRT_RENDER_STRATA_SHIFT) & MIRT_RENDER_STRATA_MASK)
 
 typedef struct mirt_render_params {
   uint32_t width;             /* Renderer::new(screen_width, ..)  renderer.rs:25-41 */

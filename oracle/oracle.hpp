@@ -93,6 +93,14 @@ inline Sampler*& tls_sampler() {
 inline float rand01() { return tls_sampler()->next(); }
 inline float rand_range(float lo, float hi) { return lo + (hi - lo) * rand01(); }
 
+// Opt-in estimator changes the device library offers beside the reference's estimator (no counterpart in the
+// reference; same bit values as the library's render flags): restated here so the tests can check them too.
+enum : uint32_t { EST_EVEN_LIGHTS = 4u, EST_DROP_NONFINITE = 8u, EST_STRATA_SHIFT = 8u, EST_STRATA_MASK = 0xFF00u };
+inline uint32_t& tls_estimator() {
+  thread_local uint32_t flags = 0;
+  return flags;
+}
+
 // ---------------------------------------------------------------------------
 // vec3.rs
 // ---------------------------------------------------------------------------
@@ -923,6 +931,16 @@ struct World final : Hittable {
     return sum;
   }
   Vec3 random(const Vec3& origin) const override {  // world.rs:112-117: type first, then object
+    if (tls_estimator() & EST_EVEN_LIGHTS) {  // opt-in: uniform over the objects, as pdf_value weighs them
+      size_t total = 0;
+      for (const auto& col : data) total += col.size();
+      uint32_t i = (uint32_t)(rand01() * (float)total);
+      if (i >= total) i = (uint32_t)total - 1;
+      for (const auto& col : data) {
+        if (i < col.size()) return col[i]->random(origin);
+        i -= (uint32_t)col.size();
+      }
+    }
     const uint32_t nt = (uint32_t)data.size();
     uint32_t ti = (uint32_t)(rand01() * (float)nt);
     if (ti >= nt) ti = nt - 1;

@@ -289,8 +289,8 @@ uint32_t oracle_scene_bvh_leaf_order(void* h, uint32_t* type_index, uint32_t* ob
 // renderer.rs:254-258 gives the RGB24 buffer).  rgb24 (optional): the encoded
 // image for `encode_spp` samples per pixel.  stats[0] = path segments traced.
 int oracle_scene_render(void* h, uint32_t width, uint32_t height, uint32_t spp, uint32_t first_sample,
-                        uint32_t max_depth, float aspect, uint64_t seed, uint32_t threads, uint8_t* rgb24,
-                        float* rgb_sum, uint64_t* stats) {
+                        uint32_t max_depth, float aspect, uint64_t seed, uint32_t threads, uint32_t estimator,
+                        uint8_t* rgb24, float* rgb_sum, uint64_t* stats) {
   Scene* s = static_cast<Scene*>(h);
   if (!s || !s->error.empty() || width < 2 || height < 2) return 1;
   const Camera camera = make_camera(*s, aspect);
@@ -310,6 +310,8 @@ int oracle_scene_render(void* h, uint32_t width, uint32_t height, uint32_t spp, 
     sampler.key[1] = (uint32_t)(seed >> 32);
     tls_sampler() = &sampler;
     tls_segments() = 0;
+    tls_estimator() = estimator;
+    const uint32_t strata = (estimator & EST_STRATA_MASK) >> EST_STRATA_SHIFT;
     for (;;) {
       const uint32_t y = next_row.fetch_add(1);
       if (y >= height) break;
@@ -319,10 +321,20 @@ int oracle_scene_render(void* h, uint32_t width, uint32_t height, uint32_t spp, 
         for (uint32_t k = 0; k < spp; ++k) {
           sampler.sample = first_sample + k;
           sampler.begin(0, STAGE_CAMERA);
-          const float u = ((float)x + rand01()) / (float)(width - 1);   // renderer.rs:216
-          const float v = ((float)y + rand01()) / (float)(height - 1);  // renderer.rs:217
+          float jx = rand01(), jy = rand01();
+          if (strata != 0) {  // opt-in: sample k stays inside cell k mod strata^2 of the pixel
+            const uint32_t cell = sampler.sample % (strata * strata);
+            jx = ((float)(cell % strata) + jx) / (float)strata;
+            jy = ((float)(cell / strata) + jy) / (float)strata;
+          }
+          const float u = ((float)x + jx) / (float)(width - 1);   // renderer.rs:216
+          const float v = ((float)y + jy) / (float)(height - 1);  // renderer.rs:217
           const Ray r = camera.get_ray(u, v);
-          color += ray_color(r, world, max_depth, 0, background, lights);
+          const Color c = ray_color(r, world, max_depth, 0, background, lights);
+          if ((estimator & EST_DROP_NONFINITE) &&
+              !(std::fabs(c.x) < INF_F && std::fabs(c.y) < INF_F && std::fabs(c.z) < INF_F))
+            continue;  // opt-in: a sample that is not finite adds nothing
+          color += c;
         }
         const size_t off = ((size_t)(height - 1 - y) * width + x) * 3;  // renderer.rs:254-255
         sum[off] = color.x; sum[off + 1] = color.y; sum[off + 2] = color.z;
@@ -330,6 +342,7 @@ int oracle_scene_render(void* h, uint32_t width, uint32_t height, uint32_t spp, 
     }
     segments.fetch_add(tls_segments());
     tls_sampler() = nullptr;
+    tls_estimator() = 0;
   };
   std::vector<std::thread> pool;
   for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(worker);

@@ -23,6 +23,17 @@ LIBEXAMPLES = PKG_DIR / "librt_examples.so"
 
 MIRT_RENDER_COUNT_WORK = 1
 MIRT_RENDER_TIME_KERNELS = 2
+# opt-in estimator changes (none has a counterpart in the reference; all off by default)
+MIRT_RENDER_EVEN_LIGHTS = 4
+MIRT_RENDER_DROP_NONFINITE = 8
+
+
+def MIRT_RENDER_STRATA(n):
+    """Render flag bits that stratify the pixel jitter over n x n cells (n in 1..255)."""
+    if not 0 <= n <= 255:
+        raise ValueError("strata per axis must be in 0..255")
+    return n << 8
+
 MIRT_KERNEL_RENDER, MIRT_KERNEL_RESOLVE, MIRT_KERNEL_COUNT = 0, 1, 4
 
 

@@ -797,8 +797,13 @@ __device__ __forceinline__ float lights_pdf_value(const ShadeTables& sc, V3 orig
   for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf_value(sc.lights[i], origin, dir);
   return sum;
 }
-__device__ __forceinline__ V3 lights_random(const ShadeTables& sc, V3 origin, Rng& rng) {
+__device__ __forceinline__ V3 lights_random(const ShadeTables& sc, V3 origin, Rng& rng, bool even) {
   if (sc.lights_mode == MIRT_LIGHTS_OBJECT) return light_random(sc.lights[0], origin, rng);
+  if (even) {  // opt-in: uniform over the objects, as lights_pdf_value weighs them
+    uint32_t i = (uint32_t)(rng_next(rng) * (float)sc.n_lights);
+    if (i >= sc.n_lights) i = sc.n_lights - 1;
+    return light_random(sc.lights[i], origin, rng);
+  }
   uint32_t g = (uint32_t)(rng_next(rng) * (float)sc.n_light_groups);
   if (g >= sc.n_light_groups) g = sc.n_light_groups - 1;
   const uint2 grp = sc.light_groups[g];
@@ -940,6 +945,9 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
   const FastDiv by_pixels{A->rc.by_pixels.m, A->rc.by_pixels.sh1, A->rc.by_pixels.sh2};
   const FastDiv by_groups{A->rc.by_groups.m, A->rc.by_groups.sh1, A->rc.by_groups.sh2};
   const FastDiv by_band{A->rc.by_band.m, A->rc.by_band.sh1, A->rc.by_band.sh2};
+  const uint32_t strata = A->rc.strata;
+  const FastDiv by_strata{A->rc.by_strata.m, A->rc.by_strata.sh1, A->rc.by_strata.sh2};
+  const FastDiv by_cells{A->rc.by_cells.m, A->rc.by_cells.sh1, A->rc.by_cells.sh2};
   // path number = pass * pixels + place in the pass; the one long division is done once for the block
   const uint32_t first_pass = (uint32_t)(first_new / pixels);
   const uint32_t first_place = (uint32_t)(first_new - (uint64_t)first_pass * pixels);
@@ -961,8 +969,15 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
     const uint32_t pixel = y * width + x;
     const uint32_t sample = first_sample + pass;
     Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, key0, key1);
-    const float u = ((float)x + rng_next(rng)) / (float)(width - 1);
-    const float v = ((float)y + rng_next(rng)) / (float)(height - 1);
+    float jx = rng_next(rng), jy = rng_next(rng);
+    if (strata != 0) {  // opt-in: sample k of a pixel stays inside cell k mod strata^2 of the pixel
+      const uint32_t cell = sample - fast_div(sample, by_cells) * (strata * strata);
+      const uint32_t cy = fast_div(cell, by_strata), cx = cell - cy * strata;
+      jx = ((float)cx + jx) / (float)strata;
+      jy = ((float)cy + jy) / (float)strata;
+    }
+    const float u = ((float)x + jx) / (float)(width - 1);    // renderer.rs:216
+    const float v = ((float)y + jy) / (float)(height - 1);   // renderer.rs:217
     // The shutter time is drawn ahead of the lens sample (camera.rs:58,66 draws it after; the draws are
     // independent): a pinhole camera, whose lens sample is multiplied by zero, then needs neither the
     // rejection loop nor a second block of random numbers.
@@ -1119,6 +1134,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
          {A->rc.background[0], A->rc.background[1], A->rc.background[2]},
          {A->rc.by_width.m, A->rc.by_width.sh1, A->rc.by_width.sh2}};
   const uint32_t cap = A->rc.region_cap;
+  const uint32_t estimator = A->rc.estimator;
   float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
   float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
   uint32_t* const region_queues = A->queues + (size_t)region * N_QUEUES * cap;
@@ -1202,7 +1218,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
             V3 dir;
             float pdf;
             if (sc.lights_mode != MIRT_LIGHTS_NONE) {
-              if (rng_next(rng) < 0.5f) dir = lights_random(sc, h.p, rng);  // pdf.rs:85-91
+              if (rng_next(rng) < 0.5f) dir = lights_random(sc, h.p, rng, (estimator & MIRT_RENDER_EVEN_LIGHTS) != 0);  // pdf.rs:85-91
               else dir = onb_local(uvw, random_cosine_direction(rng));
               const float c1 = dot(unit(dir), uvw.w);  // pdf.rs:25-32
               const float cos_pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
@@ -1245,7 +1261,9 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
           // term is zero if beta is NaN/inf so a poisoned sample blackens its
           // pixel as in the reference (renderer.rs:241-252: NaN as u8 == 0)
           const V3 cval = beta * term;
-          if (!(cval.x == 0.0f && cval.y == 0.0f && cval.z == 0.0f)) {
+          const bool dropped = (estimator & MIRT_RENDER_DROP_NONFINITE) != 0 &&
+                               !(fabsf(cval.x) < kInf && fabsf(cval.y) < kInf && fabsf(cval.z) < kInf);  // opt-in
+          if (!(cval.x == 0.0f && cval.y == 0.0f && cval.z == 0.0f) && !dropped) {
             const uint32_t y = fast_div(pixel, rc.by_width), x = pixel - y * rc.width;
             float* dst = rgb_sum + ((size_t)(rc.height - 1 - y) * rc.width + x) * 3;
             atomicAdd(dst, cval.x);

@@ -712,6 +712,10 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   rc.by_groups = make_fastdiv(std::max(1u, rc.n_groups));
   rc.by_band = make_fastdiv(p.width * 8u);
   rc.by_width = make_fastdiv(p.width);
+  rc.estimator = p.flags & (MIRT_RENDER_EVEN_LIGHTS | MIRT_RENDER_DROP_NONFINITE);
+  rc.strata = (p.flags & MIRT_RENDER_STRATA_MASK) >> MIRT_RENDER_STRATA_SHIFT;
+  rc.by_strata = make_fastdiv(std::max(1u, rc.strata));
+  rc.by_cells = make_fastdiv(std::max(1u, rc.strata * rc.strata));
   job.rgb_sum = rgb_sum_device;
   job.want_pool = p.path_pool;
   job.flags = p.flags;

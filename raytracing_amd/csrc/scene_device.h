@@ -185,6 +185,10 @@ struct RenderConst {
   // as number (j * group_stride) % n_groups; group_stride is coprime to n_groups and their product < 2^32.
   uint32_t n_groups, group_stride;
   FastDiv by_pixels, by_groups, by_band, by_width;  // / (width*height), / n_groups, / (8*width), / width
+  // opt-in estimator changes (MIRT_RENDER_EVEN_LIGHTS, MIRT_RENDER_DROP_NONFINITE) and the jitter strata per axis
+  // (0 = the reference's unstratified jitter)
+  uint32_t estimator, strata;
+  FastDiv by_strata, by_cells;  // / strata, / strata^2
 };
 
 // Path record, 64 bytes = 4 x float4:

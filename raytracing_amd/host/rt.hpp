@@ -830,6 +830,7 @@ class Renderer {
     p.max_depth = max_depth_;
     p.background[0] = background_.x; p.background[1] = background_.y; p.background[2] = background_.z;
     p.seed = seed_;
+    p.flags = estimator_;
     if (mirt_render(scene.context(), scene.scene(), &cam, &p, buffer_.data(), nullptr, &stats_) != MIRT_OK)
       return Status::err(mirt_last_error(scene.context()));
     const auto delta = std::chrono::steady_clock::now() - now;
@@ -861,6 +862,11 @@ class Renderer {
   const mirt_stats& stats() const { return stats_; }
   void set_seed(uint64_t s) { seed_ = s; }
   void set_device(int d) { device_ = d; }
+  // Opt-in estimator changes (MIRT_RENDER_EVEN_LIGHTS | MIRT_RENDER_DROP_NONFINITE | MIRT_RENDER_STRATA(n)); the
+  // reference has none of them, and with 0 (the default) the render is the reference's estimator.
+  void set_estimator(uint32_t flags) {
+    estimator_ = flags & (MIRT_RENDER_EVEN_LIGHTS | MIRT_RENDER_DROP_NONFINITE | MIRT_RENDER_STRATA_MASK);
+  }
 
  private:
   Renderer() = default;
@@ -870,6 +876,7 @@ class Renderer {
   std::vector<uint8_t> buffer_;
   mirt_stats stats_{};
   uint64_t seed_ = 7;
+  uint32_t estimator_ = 0;
   int device_ = 0;
 };
 

@@ -36,7 +36,8 @@ def lib():
     L.oracle_scene_object_count.argtypes = [C.c_void_p]
     L.oracle_scene_render.restype = C.c_int
     L.oracle_scene_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
-                                      C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+                                      C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
     L.oracle_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
     L.oracle_scene_trace.restype = C.c_int
     L.oracle_scene_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_void_p,
@@ -96,13 +97,14 @@ class Scene:
                                    bg.ctypes.data_as(C.POINTER(C.c_float)))
         return cam, bg
 
-    def render(self, width, height, spp, depth=None, aspect=0.0, seed=7, first_sample=0, threads=0):
-        """Returns (rgb24 HxWx3 u8, sums HxWx3 f32, segments traced)."""
+    def render(self, width, height, spp, depth=None, aspect=0.0, seed=7, first_sample=0, threads=0, estimator=0):
+        """Returns (rgb24 HxWx3 u8, sums HxWx3 f32, segments traced).  `estimator`: the opt-in estimator bits of
+        the device library's render flags (even lights 4, drop non-finite samples 8, jitter strata per axis << 8)."""
         rgb = np.zeros((height, width, 3), np.uint8)
         sums = np.zeros((height, width, 3), np.float32)
         stats = np.zeros(1, np.uint64)
         rc = self.L.oracle_scene_render(self.h, width, height, spp, first_sample,
-                                        self.depth if depth is None else depth, aspect, seed, threads,
+                                        self.depth if depth is None else depth, aspect, seed, threads, estimator,
                                         _ptr(rgb), _ptr(sums), _ptr(stats))
         if rc != 0:
             raise RuntimeError("oracle render failed")
