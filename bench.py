@@ -4,7 +4,9 @@
 One "step" is one full render of the frame: every rank (one process per GPU) traces its
 share of the samples of every pixel into an f32 sum image resident in HBM, the sums are
 reduced to rank 0 over RCCL (only when N > 1) and rank 0 encodes the RGB24 image
-(renderer.rs:232-259).  Total work per step is fixed, so scaling is "strong".
+(renderer.rs:232-259).  By default every GPU traces `--spp` samples per pixel, so an N-GPU step is the
+frame at N x spp samples per pixel (scaling "weak": the work per GPU is fixed and no rank waits for another
+before the one reduce); `--scaling strong` splits the same `--spp` over the ranks instead.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -40,6 +42,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=0, help="0 = the example's own max depth")
     ap.add_argument("--pool", type=int, default=0, help="paths in flight per GPU (0 = library default)")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N GPUs: weak = --spp samples per pixel on every GPU, strong = --spp split over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--save", default="", help="write the last frame as PPM (rank 0)")
@@ -98,7 +102,8 @@ def main():
     depth = a.depth or scene.depth
     aspect = a.width / a.height
     # sample-range sharding: rank r renders samples [first, first + count) of every pixel
-    first, count = R.shard_samples(a.spp, world, rank)
+    total_spp = a.spp * world if a.scaling == "weak" else a.spp
+    first, count = R.shard_samples(total_spp, world, rank)
 
     sums = torch.zeros((a.height, a.width, 3), dtype=torch.float32, device=dev)
     rgb = torch.zeros((a.height, a.width, 3), dtype=torch.uint8, device=dev)
@@ -115,7 +120,7 @@ def main():
         if world > 1:
             dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
-            scene.resolve(sums.data_ptr(), a.width, a.height, a.spp, rgb.data_ptr(), stream=stream)
+            scene.resolve(sums.data_ptr(), a.width, a.height, total_spp, rgb.data_ptr(), stream=stream)
         return st
 
     def fence():
@@ -147,7 +152,7 @@ def main():
 
     result = None
     if rank == 0:
-        samples_per_step = a.width * a.height * a.spp
+        samples_per_step = a.width * a.height * total_spp
         value = samples_per_step * a.steps / elapsed / 1e6
         # work per segment, from an instrumented pass outside the timed region (rank 0's share, few spp)
         probe_spp = max(1, min(count, 4))
@@ -191,8 +196,8 @@ def main():
         result = {
             "metric": "Msamples/s on final_scene 1080p", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.scene} {a.width}x{a.height}, {a.spp} spp, depth {depth}",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.scene} {a.width}x{a.height}, {total_spp} spp, depth {depth}",
                        "sharding": f"sample ranges over {world} GPU(s), RCCL sum-reduce of the f32 image" if world > 1
                        else "single GPU", "path_pool": ws["path_pool"], "seed": a.seed,
                        "rounds_per_step": iterations / max(1, a.steps)},
