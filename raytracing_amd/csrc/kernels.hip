@@ -289,9 +289,12 @@ __device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min
   const float l = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))),
                         fmaxf(fabsf(lo.z), fabsf(hi.z)));
   const float pad = l * kBoxPad;
-  const float x0 = (lo.x - pad) * inv.x, x1 = (hi.x + pad) * inv.x;
-  const float y0 = (lo.y - pad) * inv.y, y1 = (hi.y + pad) * inv.y;
-  const float z0 = (lo.z - pad) * inv.z, z1 = (hi.z + pad) * inv.z;
+  // (lo - pad) * inv and (hi + pad) * inv, the padding folded into one fused multiply-add per plane (this
+  // test only has to be conservative; its rounding is far inside the padding)
+  const float ex = pad * inv.x, ey = pad * inv.y, ez = pad * inv.z;
+  const float x0 = __builtin_fmaf(lo.x, inv.x, -ex), x1 = __builtin_fmaf(hi.x, inv.x, ex);
+  const float y0 = __builtin_fmaf(lo.y, inv.y, -ey), y1 = __builtin_fmaf(hi.y, inv.y, ey);
+  const float z0 = __builtin_fmaf(lo.z, inv.z, -ez), z1 = __builtin_fmaf(hi.z, inv.z, ez);
   // fminf/fmaxf drop a NaN operand (0 * inf on a slab face): the axis then does not constrain
   const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), t_min));
   const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
