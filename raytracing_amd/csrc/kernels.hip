@@ -859,6 +859,8 @@ __device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t 
 // ---- render -----------------------------------------------------------------------
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
+constexpr uint32_t LDS_LIGHTS = 8;
+
 // Block-shared bookkeeping of one region's loop, written by thread 0 between barriers.
 struct RenderShared {
   uint32_t n_fresh;                     // camera paths started this round, in the slots after the survivors
@@ -871,8 +873,10 @@ struct RenderShared {
   uint32_t late_n[N_QUEUES];            // entries appended to each queue for the second shading pass
   uint32_t pad[3];
   MediumEntry media[MIRT_MAX_MEDIA];
+  DLight lights[LDS_LIGHTS];            // the scene's light list, when it is this short
+  uint2 light_groups[LDS_LIGHTS];
 };
-static_assert(sizeof(RenderShared) % 16 == 0, "keeps the node array 16-byte aligned");
+constexpr size_t SHARED_BYTES = (sizeof(RenderShared) + 255) / 256 * 256;  // the node array starts on an LDS row
 
 // The launch arguments live in device memory.  Each phase of the kernel reads what it needs through this:
 // the empty asm hides where the address came from, so the compiler cannot move those loads up to the start of
@@ -902,7 +906,7 @@ struct RenderLds {
   float4* textures;   // two quads per texture (DTexture)
   Slot* stack;  // this thread's column; rows are RENDER_THREADS entries apart
   __device__ __forceinline__ RenderLds(float4* smem, ConstArgs A) {
-    float4* after = smem + sizeof(RenderShared) / 16;
+    float4* after = smem + SHARED_BYTES / 16;
     nodes = after;
     prims = nodes + (LDS_SCENE ? A->sc.n_nodes * 4u : 0u);
     ops = prims + (LDS_SCENE ? A->sc.n_prims * PRIM_QUADS_LDS : 0u);
@@ -910,7 +914,9 @@ struct RenderLds {
     const bool shading = LDS_SCENE && A->lds_shading != 0;
     materials = chains + (LDS_SCENE ? A->sc.n_chains * 2u : 0u);
     textures = materials + (shading ? A->sc.n_materials : 0u);
-    stack = reinterpret_cast<Slot*>(textures + (shading ? A->sc.n_textures * 2u : 0u)) + threadIdx.x;
+    // the stacks start on an LDS row: a wave's 64 entries of one level then lie in one row
+    const uint32_t tables_end = (uint32_t)((textures + (shading ? A->sc.n_textures * 2u : 0u)) - smem);  // in quads
+    stack = reinterpret_cast<Slot*>(smem + ((tables_end + 15u) & ~15u)) + threadIdx.x;
   }
   // the tables the walk and the shading read the scene's geometry from
   __device__ __forceinline__ SceneTables tables(ConstArgs A) const {
@@ -1129,6 +1135,10 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
   if (LDS_SCENE && A->lds_shading != 0) {  // the block's own copies
     sc.materials = reinterpret_cast<const DMaterial*>(lds.materials);
     sc.textures = reinterpret_cast<const DTexture*>(lds.textures);
+  }
+  if (sc.n_lights <= LDS_LIGHTS && sc.n_light_groups <= LDS_LIGHTS) {
+    sc.lights = sh.lights;
+    sc.light_groups = sh.light_groups;
   }
   const SceneTables gt = MIRT_GLOBAL_TABLES(A->sc);
   const uint32_t n_media = A->sc.n_media;
@@ -1377,6 +1387,10 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
   {
     ConstArgs A = pinned(args);
     stage_media(A->sc.n_media, A->sc.media, A->sc.prims, sh.media);
+    if (A->sc.n_lights <= LDS_LIGHTS && A->sc.n_light_groups <= LDS_LIGHTS) {
+      if (threadIdx.x < A->sc.n_lights) sh.lights[threadIdx.x] = A->sc.lights[threadIdx.x];
+      if (threadIdx.x < A->sc.n_light_groups) sh.light_groups[threadIdx.x] = A->sc.light_groups[threadIdx.x];
+    }
     if (LDS_SCENE) {
       const RenderLds<true> lds(smem, A);
       const float4 *nodes = A->sc.nodes, *prims = A->sc.prims, *chain_ops = A->sc.chain_ops;
@@ -1509,20 +1523,22 @@ RenderConfig plan_render(const DeviceScene& sc) {
   const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * PRIM_QUADS_LDS * 16 +
                              (size_t)sc.n_chain_ops * 16 + (size_t)sc.n_chains * 32;
   // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes
-  const size_t lds_total = sizeof(RenderShared) + scene_bytes + (size_t)depth * RENDER_THREADS * 2;
-  if (lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
+  const auto lds_total = [&](size_t table_bytes) {  // bookkeeping, tables, then the stacks on a row of their own
+    return SHARED_BYTES + (table_bytes + 255) / 256 * 256 + (size_t)depth * RENDER_THREADS * 2;
+  };
+  if (lds_total(scene_bytes) <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
     cfg.lds_scene = true;
     cfg.stack_depth = depth;
-    cfg.lds_bytes = lds_total;
+    cfg.lds_bytes = lds_total(scene_bytes);
     const size_t shading_bytes = (size_t)sc.n_materials * sizeof(DMaterial) + (size_t)sc.n_textures * sizeof(DTexture);
-    if (lds_total + shading_bytes <= LDS_BYTES_PER_CU && !std::getenv("MIRT_NO_LDS_SHADING")) {
+    if (lds_total(scene_bytes + shading_bytes) <= LDS_BYTES_PER_CU && !std::getenv("MIRT_NO_LDS_SHADING")) {
       cfg.lds_shading = true;
-      cfg.lds_bytes += shading_bytes;
+      cfg.lds_bytes = lds_total(scene_bytes + shading_bytes);
     }
   } else {
     cfg.lds_scene = false;
     cfg.stack_depth = STACK_DEPTH;
-    cfg.lds_bytes = sizeof(RenderShared) + (size_t)STACK_DEPTH * RENDER_THREADS * 4;
+    cfg.lds_bytes = SHARED_BYTES + (size_t)STACK_DEPTH * RENDER_THREADS * 4;
   }
   cfg.refill_min = 32;
   cfg.node_min = 16;
