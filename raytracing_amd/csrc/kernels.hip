@@ -1031,7 +1031,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_
   const uint32_t lane = lane_id();
   const uint32_t cap = A->rc.region_cap;
   float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
-  uint32_t* const region_queues = A->queues + (size_t)region * N_QUEUES * cap;  // queue q at [q * cap, (q + 1) * cap)
+  // queue q of the region: 64-byte records at [q * cap, (q + 1) * cap)
+  float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   const uint32_t root = RC::encode(A->sc.root_ref);
   const uint32_t refill_min = A->refill_min, node_min = A->node_min;
   Work work{};
@@ -1040,6 +1041,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_
   Walk w;
   w.cur = RC::NONE;
   uint32_t slot = NO_SLOT;  // slot of the ray this lane is walking
+  float4 state = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // what the record holds besides the ray: throughput, sample | bounce
+  float pixel_bits = 0.0f;
   bool more = true;         // rays left to hand out, as far as this wave knows
   // Every turn of this loop the wave first hands in finished rays and fetches new ones if enough lanes
   // are without work, then steps down the tree until (almost) every lane holds a leaf, then tests one
@@ -1074,9 +1077,12 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_
       const uint32_t bq = __shfl(got, q < 0 ? 0 : q);  // every lane takes part: the reserving lanes may not be done
       if (done) {
         const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
-        region_queues[(size_t)q * cap + pos] = slot;
-        cur[4 * (size_t)slot + 3] =
-            make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), 0.0f);
+        // the whole path record moves into the queue, hit included: shading reads its queue front to back
+        float4* const out = region_queues + 4 * ((size_t)q * cap + pos);
+        out[0] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, w.r.time);
+        out[1] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, pixel_bits);
+        out[2] = state;
+        out[3] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), 0.0f);
         slot = NO_SLOT;
         ++segments;
       }
@@ -1089,6 +1095,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_
         if (slot == NO_SLOT && entry < total) {
           slot = entry;
           const float4 r0 = cur[4 * (size_t)slot], r1 = cur[4 * (size_t)slot + 1];
+          state = cur[4 * (size_t)slot + 2];
+          pixel_bits = r1.w;
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
           walk_begin(w, r, root);
@@ -1148,9 +1156,8 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
          {A->rc.by_width.m, A->rc.by_width.sh1, A->rc.by_width.sh2}};
   const uint32_t cap = A->rc.region_cap;
   const uint32_t estimator = A->rc.estimator;
-  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
   float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
-  uint32_t* const region_queues = A->queues + (size_t)region * N_QUEUES * cap;
+  float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   float* const rgb_sum = A->rgb_sum;
   // The walk queued every ray under the material of the surface it found.  A constant medium in front of that
   // surface changes the material, so shading takes two passes: the first gives the media their chance, shades
@@ -1178,15 +1185,15 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
 #pragma unroll
       for (int k = 1; k < N_QUEUES; ++k)
         if (batch >= last_batch[k - 1]) { q = k; n_q = count[k]; e0 = (batch - last_batch[k - 1]) << 6; from = first[k]; }
-      const uint32_t* entries = region_queues + (size_t)q * cap + from;
+      float4* const entries = region_queues + 4 * ((size_t)q * cap + from);
       const uint32_t e = e0 + lane;
       bool alive = false;
       Ray nr;
       V3 beta = v3(0.0f, 0.0f, 0.0f);
       uint32_t pixel = 0, sample = 0, bounce = 0;
       if (e < n_q) {
-        const size_t i = entries[e];
-        const float4 r0 = cur[4 * i], r1 = cur[4 * i + 1], r2 = cur[4 * i + 2], r3 = cur[4 * i + 3];
+        const float4* const rec = entries + 4 * (size_t)e;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
         Ray r;
         r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
         pixel = __float_as_uint(r1.w);
@@ -1205,9 +1212,10 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
             const uint32_t to_q = (uint32_t)queue_of(material);
             if (to_q != q) {  // another material's code: goes to the end of that queue, for the second pass
               deferred = true;
-              cur[4 * i + 3] = make_float4(t, __uint_as_float(ref), r3.z, r3.w);
               const uint32_t at = sh.queue_n[to_q] + atomicAdd(&sh.late_n[to_q], 1u);
-              region_queues[(size_t)to_q * cap + at] = (uint32_t)i;
+              float4* const out = region_queues + 4 * ((size_t)to_q * cap + at);
+              out[0] = r0; out[1] = r1; out[2] = r2;
+              out[3] = make_float4(t, __uint_as_float(ref), r3.z, r3.w);
             }
           }
         }
@@ -1332,17 +1340,16 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, bool odd) {
   const uint2* const prim_ids = A->sc.prim_ids;
   const uint32_t key0 = A->rc.key0, key1 = A->rc.key1;
   const uint32_t cap = A->rc.region_cap;
-  const float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)blockIdx.x * cap;
-  const uint32_t* const region_queues = A->queues + (size_t)blockIdx.x * N_QUEUES * cap;
+  const float4* const region_queues = A->queues + 4 * (size_t)blockIdx.x * N_QUEUES * cap;
   uint32_t* const hit_type = A->hit_type;
   uint32_t* const hit_object = A->hit_object;
   float* const hit_t = A->hit_t;
   for (uint32_t q = 0; q < N_QUEUES; ++q) {
     const uint32_t n_q = sh.queue_n[q];
-    const uint32_t* entries = region_queues + (size_t)q * cap;
+    const float4* entries = region_queues + 4 * (size_t)q * cap;
     for (uint32_t e = threadIdx.x; e < n_q; e += RENDER_THREADS) {
-      const size_t i = entries[e];
-      const float4 r0 = cur[4 * i], r1 = cur[4 * i + 1], r3 = cur[4 * i + 3];
+      const float4* const rec = entries + 4 * (size_t)e;
+      const float4 r0 = rec[0], r1 = rec[1], r3 = rec[3];
       Ray r;
       r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
       const uint32_t g = __float_as_uint(r1.w);

@@ -595,7 +595,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
 
   MIRT_HIP(ctx, ctx->paths[0].ensure((size_t)pool * 64));
   MIRT_HIP(ctx, ctx->paths[1].ensure((size_t)pool * 64));
-  MIRT_HIP(ctx, ctx->queues.ensure((size_t)pool * 4 * N_QUEUES));
+  MIRT_HIP(ctx, ctx->queues.ensure((size_t)pool * 64 * N_QUEUES));
   MIRT_HIP(ctx, ctx->state.ensure(sizeof(RenderState)));
   MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
   MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
@@ -627,7 +627,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.rc = job.rc;
   args.paths_a = ctx->paths[0].as<float4>();
   args.paths_b = ctx->paths[1].as<float4>();
-  args.queues = ctx->queues.as<uint32_t>();
+  args.queues = ctx->queues.as<float4>();
   args.state = ctx->state.as<RenderState>();
   args.work = ctx->work.as<WorkCounters>();
   args.rgb_sum = job.rgb_sum;

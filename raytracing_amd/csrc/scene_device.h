@@ -197,7 +197,8 @@ struct RenderConst {
 //   r2 = throughput.rgb, bits(sample index << 8 | bounce)
 //   r3 = t of the closest surface, bits(hit ref), bits(side of a box hit), -     (the only part the walk writes
 //        for a surviving path)
-// Material queue q of region s holds slot numbers (within the region) at queues[(s * N_QUEUES + q) * region_cap ...].
+// Shading queue q of region s holds whole path records (the walk moves a finished ray's record there, hit
+// included) at queues[4 * (s * N_QUEUES + q) * region_cap ...]: shading reads a queue front to back.
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
 constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
@@ -222,7 +223,7 @@ struct RenderArgs {
   RenderConst rc;
   float4* paths_a;   // the two buffers of path records, pool * 64 bytes each
   float4* paths_b;
-  uint32_t* queues;  // pool * N_QUEUES slot numbers
+  float4* queues;    // pool * N_QUEUES path records with their hits, 64 bytes each
   RenderState* state;
   WorkCounters* work;
   float* rgb_sum;
