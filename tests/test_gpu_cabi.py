@@ -28,7 +28,7 @@ class Ctx:
         return self.L.mirt_last_error(self.ctx).decode()
 
     def upload(self, spheres=(), rects=(), boxes=(), moving=(), materials=None, textures=None, chains=None,
-               chain_ops=(), media=(), time=(0.0, 1.0), expect=0):
+               chain_ops=(), media=(), time=(0.0, 1.0), expect=0, lights=(), light_groups=(), lights_mode=0):
         keep = []
 
         def arr(T, items):
@@ -48,6 +48,9 @@ class Ctx:
         d.materials, d.n_materials = arr(R.Material, materials), len(materials)
         d.textures, d.n_textures = arr(R.Texture, textures), len(textures)
         d.media, d.n_media = arr(R.Medium, media), len(media)
+        d.lights, d.n_lights = arr(R.Light, lights), len(lights)
+        d.light_groups, d.n_light_groups = arr(R.LightGroup, light_groups), len(light_groups)
+        d.lights_mode = lights_mode
         d.time0, d.time1 = time
         scene = C.c_void_p()
         rc = self.L.mirt_scene_upload(self.ctx, C.byref(d), C.byref(scene))
@@ -65,9 +68,9 @@ class Ctx:
         assert rc == expect, (rc, self.error())
         return ti, oi, t
 
-    def render(self, scene, w, h, spp, depth=5, bg=(0.25, 0.5, 1.0), expect=0, cam=None):
+    def render(self, scene, w, h, spp, depth=5, bg=(0.25, 0.5, 1.0), expect=0, cam=None, flags=0):
         cam = cam or simple_camera()
-        p = R.RenderParams(w, h, spp, 0, depth, (C.c_float * 3)(*bg), 9, 0, 0)
+        p = R.RenderParams(w, h, spp, 0, depth, (C.c_float * 3)(*bg), 9, 0, flags)
         rgb = np.zeros((h, w, 3), np.uint8)
         sums = np.zeros((h, w, 3), F)
         st = R.Stats()
@@ -231,3 +234,31 @@ def test_constant_medium_inside_a_box_boundary(ctx):
     rgb, sums, _ = ctx.render(scene, 32, 32, 4, bg=(1.0, 1.0, 1.0))
     assert np.all(sums[14:18, 14:18] == 0.0)
     assert np.all(sums[0, :] > 0.0)
+
+
+def test_long_light_lists_sample_the_same_light(ctx):
+    """A lit floor under one downward-facing rect light, with the light list given three ways: the bare object, a
+    World of 12 copies of it in one type group (longer than the list the kernel keeps on chip), and that World
+    sampled evenly.  Copies of one light change neither World::random nor the mean of pdf_value
+    (world.rs:100-117), so the three renders estimate the same image."""
+    mats = [R.Material(0, 0, 0.0), R.Material(3, 1, 0.0)]                                  # grey lambertian, light
+    tex = [R.Texture(0, (C.c_float * 3)(0.5, 0.5, 0.5), 0, 0, 0.0, 0), R.Texture(0, (C.c_float * 3)(8.0, 8.0, 8.0), 0, 0, 0.0, 0)]
+    ops = [R.ChainOp(2, (C.c_float * 3)(0, 0, 0))]                                         # FlipFace: emits downwards
+    chains = [R.Chain(0, 0), R.Chain(0, 1)]
+    floor = R.Rect(hdr(0, 0, 0), 1, -4.0, 4.0, -8.0, 0.0, -1.0)                            # XZ rect at y = -1
+    lamp = R.Rect(hdr(1, 1, 0, material=1, chain=1), 1, -1.0, 1.0, -5.0, -3.0, 1.5)        # XZ rect at y = 1.5
+    light = R.Light(0, (C.c_float * 5)(-1.0, 1.0, -5.0, -3.0, 1.5))
+    kw = dict(rects=[floor, lamp], materials=mats, textures=tex, chains=chains, chain_ops=ops)
+    one = ctx.upload(lights=[light], lights_mode=1, **kw)
+    many = ctx.upload(lights=[light] * 12, light_groups=[R.LightGroup(0, 12)], lights_mode=2, **kw)
+    cam = simple_camera()
+    cam.origin[:] = [0, 0.5, 0]
+    cam.lower_left_corner[:] = [-1, -1.5, -1]                                              # looks a little downwards
+    images = [ctx.render(s, 48, 48, 64, depth=3, bg=(0, 0, 0), cam=cam, flags=f)[1]
+              for s, f in ((one, 0), (many, 0), (many, R.MIRT_RENDER_EVEN_LIGHTS))]
+    lit = images[0][30:, :, :]                                                             # bottom rows: the floor
+    assert np.isfinite(lit).all() and lit.mean() > 0.5
+    for other in images[1:]:
+        assert np.isfinite(other).all()
+        assert not np.array_equal(other, images[0])
+        assert abs(other[30:].mean() - lit.mean()) < 0.03 * lit.mean()
