@@ -891,6 +891,15 @@ __device__ __forceinline__ ConstArgs pinned(const RenderArgs* p) {
   asm volatile("" : "+s"(v));
   return (ConstArgs)v;
 }
+// The block's LDS as the phases of the kernel get it: the kernel passes the address down.  A function that
+// names the dynamic LDS array itself has to look its offset up in a per-kernel table in memory, and the compiler
+// repeats that scalar load wherever it needs the address again (inside the tree-step loop, for one).
+// (It travels as a plain number taken through an empty asm in the kernel, or the compiler sees that every caller
+// passes the same array and puts the lookup back.)
+typedef __attribute__((address_space(3))) float4* LdsQuads;
+__device__ __forceinline__ float4* lds_base(uint32_t address) {
+  return (float4*)(LdsQuads)(uintptr_t)uniform(address);
+}
 
 // Dynamic shared memory of the render kernel: [RenderShared][nodes][48-byte primitive records][chain ops]
 // [chains][materials][textures][stack] when the scene is staged (LDS_SCENE; materials and textures only if
@@ -1014,10 +1023,10 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
 // queue of the material hit.  Lanes whose ray has finished pull the region's next ray instead of waiting for
 // the slowest lane of the wave.
 template <bool COUNT, bool LDS_SCENE>
-__device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_t total, Work* work_out,
+__device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg, bool odd, uint32_t total, Work* work_out,
                                        uint32_t* segments_out) {
   constexpr int THREADS = RENDER_THREADS;
-  extern __shared__ float4 smem[];
+  float4* const smem = lds_base(lds_arg);
   RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
   using RC = RefCode<LDS_SCENE>;
   constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
@@ -1129,8 +1138,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, bool odd, uint32_
 // Shades the region's four queues (renderer.rs:141-212): constant media get their chance, the material
 // scatters or ends the path, survivors are packed into the first slots of the region's other buffer.
 template <bool COUNT, bool LDS_SCENE>
-__device__ __noinline__ void shade_queues(const RenderArgs* args, bool odd) {
-  extern __shared__ float4 smem[];
+__device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_arg, bool odd) {
+  float4* const smem = lds_base(lds_arg);
   RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
   constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
   ConstArgs A = pinned(args);
@@ -1327,8 +1336,8 @@ __device__ __noinline__ void start_rays(const RenderArgs* args, bool odd, uint32
 // ... and once the walk has found its closest surface (and the media had their chance, with the draws of
 // path (g, sample 0, bounce 0)), what it hit is written to the caller's arrays; no ray goes on.
 template <bool LDS_SCENE>
-__device__ __noinline__ void report_hits(const RenderArgs* args, bool odd) {
-  extern __shared__ float4 smem[];
+__device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_arg, bool odd) {
+  float4* const smem = lds_base(lds_arg);
   RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
   ConstArgs A = pinned(args);
   odd = uniform(odd) != 0;
@@ -1391,6 +1400,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
   constexpr int THREADS = RENDER_THREADS;
   extern __shared__ float4 smem[];
   RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  uint32_t lds_address = (uint32_t)(uintptr_t)(LdsQuads)smem;
+  asm volatile("" : "+s"(lds_address));
   {
     ConstArgs A = pinned(args);
     stage_media(A->sc.n_media, A->sc.media, A->sc.prims, sh.media);
@@ -1465,11 +1476,11 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     else start_paths<COUNT>(args, odd, n_surv, n_fresh, ((uint64_t)sh.first_new_hi << 32) | sh.first_new_lo);
     if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
     __syncthreads();  // the new rays are visible to the whole block
-    walk_rays<COUNT, LDS_SCENE>(args, odd, total, &work, &segments);
+    walk_rays<COUNT, LDS_SCENE>(args, lds_address, odd, total, &work, &segments);
     __syncthreads();  // every live slot carries its surface hit and sits in one of the four queues
     if (COUNT) ts = clock64();
-    if (tracing) report_hits<LDS_SCENE>(args, odd);
-    else shade_queues<COUNT, LDS_SCENE>(args, odd);
+    if (tracing) report_hits<LDS_SCENE>(args, lds_address, odd);
+    else shade_queues<COUNT, LDS_SCENE>(args, lds_address, odd);
     if (COUNT) work.cycles[MIRT_PHASE_SHADE] += clock64() - ts;
     __syncthreads();
     n_surv = sh.n_next;
