@@ -18,7 +18,8 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 ROOT = PKG_DIR.parent
 ASSET_DIR = PKG_DIR / "assets"
-LIBMIRT = PKG_DIR / "libmirt.so"
+# MIRT_LIBMIRT names another build of the library (kernel A/B comparisons on one GPU box)
+LIBMIRT = Path(os.environ["MIRT_LIBMIRT"]) if os.environ.get("MIRT_LIBMIRT") else PKG_DIR / "libmirt.so"
 LIBEXAMPLES = PKG_DIR / "librt_examples.so"
 
 MIRT_RENDER_COUNT_WORK = 1

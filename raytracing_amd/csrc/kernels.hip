@@ -793,26 +793,42 @@ __device__ __forceinline__ V3 light_random(const DLight& l, V3 origin, Rng& rng)
   return v3(1.0f, 0.0f, 0.0f);
 }
 // HittablePdf over the `lights` argument (pdf.rs:56-67, world.rs:100-117)
-__device__ __forceinline__ float lights_pdf_value(const ShadeTables& sc, V3 origin, V3 dir) {
-  if (sc.lights_mode == MIRT_LIGHTS_OBJECT) return light_pdf_value(sc.lights[0], origin, dir);
-  const float weight = 1.0f / (float)sc.n_lights;
+struct LightList {
+  const DLight* lights;
+  const uint2* groups;  // (first_light, n_lights)
+  uint32_t mode, n_lights, n_groups;
+};
+__device__ __forceinline__ float lights_pdf_value(const LightList& ll, V3 origin, V3 dir) {
+  if (ll.mode == MIRT_LIGHTS_OBJECT) return light_pdf_value(ll.lights[0], origin, dir);
+  const float weight = 1.0f / (float)ll.n_lights;
   float sum = 0.0f;
-  for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf_value(sc.lights[i], origin, dir);
+  for (uint32_t i = 0; i < ll.n_lights; ++i) sum += weight * light_pdf_value(ll.lights[i], origin, dir);
   return sum;
 }
-__device__ __forceinline__ V3 lights_random(const ShadeTables& sc, V3 origin, Rng& rng, bool even) {
-  if (sc.lights_mode == MIRT_LIGHTS_OBJECT) return light_random(sc.lights[0], origin, rng);
+__device__ __forceinline__ V3 lights_random(const LightList& ll, V3 origin, Rng& rng, bool even) {
+  if (ll.mode == MIRT_LIGHTS_OBJECT) return light_random(ll.lights[0], origin, rng);
   if (even) {  // opt-in: uniform over the objects, as lights_pdf_value weighs them
-    uint32_t i = (uint32_t)(rng_next(rng) * (float)sc.n_lights);
-    if (i >= sc.n_lights) i = sc.n_lights - 1;
-    return light_random(sc.lights[i], origin, rng);
+    uint32_t i = (uint32_t)(rng_next(rng) * (float)ll.n_lights);
+    if (i >= ll.n_lights) i = ll.n_lights - 1;
+    return light_random(ll.lights[i], origin, rng);
   }
-  uint32_t g = (uint32_t)(rng_next(rng) * (float)sc.n_light_groups);
-  if (g >= sc.n_light_groups) g = sc.n_light_groups - 1;
-  const uint2 grp = sc.light_groups[g];
+  uint32_t g = (uint32_t)(rng_next(rng) * (float)ll.n_groups);
+  if (g >= ll.n_groups) g = ll.n_groups - 1;
+  const uint2 grp = ll.groups[g];
   uint32_t i = (uint32_t)(rng_next(rng) * (float)grp.y);
   if (i >= grp.y) i = grp.y - 1;
-  return light_random(sc.lights[grp.x + i], origin, rng);
+  return light_random(ll.lights[grp.x + i], origin, rng);
+}
+// One draw of the mixture of the light list and the cosine lobe around uvw.w, and its density (pdf.rs:81-91,
+// renderer.rs:166-173).
+__device__ __forceinline__ V3 mixture_sample(const LightList& ll, const Onb& uvw, V3 p, Rng& rng, bool even, float& pdf) {
+  V3 dir;
+  if (rng_next(rng) < 0.5f) dir = lights_random(ll, p, rng, even);  // pdf.rs:85-91
+  else dir = onb_local(uvw, random_cosine_direction(rng));
+  const float c1 = dot(unit(dir), uvw.w);  // pdf.rs:25-32
+  const float cos_pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
+  pdf = 0.5f * lights_pdf_value(ll, p, dir) + 0.5f * cos_pdf;  // pdf.rs:81-83
+  return dir;
 }
 
 __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {  // material.rs:105-108
@@ -859,8 +875,6 @@ __device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t 
 // ---- render -----------------------------------------------------------------------
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
-constexpr uint32_t LDS_LIGHTS = 8;
-
 // Block-shared bookkeeping of one region's loop, written by thread 0 between barriers.
 struct RenderShared {
   uint32_t n_fresh;                     // camera paths started this round, in the slots after the survivors
@@ -873,8 +887,6 @@ struct RenderShared {
   uint32_t late_n[N_QUEUES];            // entries appended to each queue for the second shading pass
   uint32_t pad[3];
   MediumEntry media[MIRT_MAX_MEDIA];
-  DLight lights[LDS_LIGHTS];            // the scene's light list, when it is this short
-  uint2 light_groups[LDS_LIGHTS];
 };
 constexpr size_t SHARED_BYTES = (sizeof(RenderShared) + 255) / 256 * 256;  // the node array starts on an LDS row
 
@@ -902,17 +914,19 @@ __device__ __forceinline__ float4* lds_base(uint32_t address) {
 }
 
 // Dynamic shared memory of the render kernel: [RenderShared][nodes][48-byte primitive records][chain ops]
-// [chains][materials][textures][stack] when the scene is staged (LDS_SCENE; materials and textures only if
-// args.lds_shading says they fit as well), else [RenderShared][stack].
+// [chains][materials][textures][lights][light groups][stack] when the scene is staged (LDS_SCENE), else
+// [RenderShared][stack].
 template <bool LDS_SCENE>
 struct RenderLds {
   using Slot = typename std::conditional<LDS_SCENE, uint16_t, uint32_t>::type;
   float4* nodes;
   float4* prims;
   float4* ops;
-  float4* chains;  // two quads per chain
+  float4* chains;     // two quads per chain
   float4* materials;  // one quad per material (DMaterial)
   float4* textures;   // two quads per texture (DTexture)
+  float4* lights;     // two quads per light (DLight)
+  float4* groups;     // light groups, two to a quad
   Slot* stack;  // this thread's column; rows are RENDER_THREADS entries apart
   __device__ __forceinline__ RenderLds(float4* smem, ConstArgs A) {
     float4* after = smem + SHARED_BYTES / 16;
@@ -920,11 +934,12 @@ struct RenderLds {
     prims = nodes + (LDS_SCENE ? A->sc.n_nodes * 4u : 0u);
     ops = prims + (LDS_SCENE ? A->sc.n_prims * PRIM_QUADS_LDS : 0u);
     chains = ops + (LDS_SCENE ? A->sc.n_chain_ops : 0u);
-    const bool shading = LDS_SCENE && A->lds_shading != 0;
     materials = chains + (LDS_SCENE ? A->sc.n_chains * 2u : 0u);
-    textures = materials + (shading ? A->sc.n_materials : 0u);
+    textures = materials + (LDS_SCENE ? A->sc.n_materials : 0u);
+    lights = textures + (LDS_SCENE ? A->sc.n_textures * 2u : 0u);
+    groups = lights + (LDS_SCENE ? A->sc.n_lights * 2u : 0u);
     // the stacks start on an LDS row: a wave's 64 entries of one level then lie in one row
-    const uint32_t tables_end = (uint32_t)((textures + (shading ? A->sc.n_textures * 2u : 0u)) - smem);  // in quads
+    const uint32_t tables_end = (uint32_t)((groups + (LDS_SCENE ? (A->sc.n_light_groups + 1u) / 2u : 0u)) - smem);  // in quads
     stack = reinterpret_cast<Slot*>(smem + ((tables_end + 15u) & ~15u)) + threadIdx.x;
   }
   // the tables the walk and the shading read the scene's geometry from
@@ -1149,14 +1164,13 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
   const uint32_t region = blockIdx.x;
   const uint32_t lane = lane_id();
   ShadeTables sc = MIRT_SHADE_TABLES(A->sc);
-  if (LDS_SCENE && A->lds_shading != 0) {  // the block's own copies
+  if (LDS_SCENE) {  // the block's own copies
     sc.materials = reinterpret_cast<const DMaterial*>(lds.materials);
     sc.textures = reinterpret_cast<const DTexture*>(lds.textures);
+    sc.lights = reinterpret_cast<const DLight*>(lds.lights);
+    sc.light_groups = reinterpret_cast<const uint2*>(lds.groups);
   }
-  if (sc.n_lights <= LDS_LIGHTS && sc.n_light_groups <= LDS_LIGHTS) {
-    sc.lights = sh.lights;
-    sc.light_groups = sh.light_groups;
-  }
+  const LightList ll{sc.lights, sc.light_groups, sc.lights_mode, sc.n_lights, sc.n_light_groups};
   const SceneTables gt = MIRT_GLOBAL_TABLES(A->sc);
   const uint32_t n_media = A->sc.n_media;
   struct { uint32_t width, height, max_depth, key0, key1; float background[3]; FastDiv by_width; }
@@ -1248,11 +1262,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
             V3 dir;
             float pdf;
             if (sc.lights_mode != MIRT_LIGHTS_NONE) {
-              if (rng_next(rng) < 0.5f) dir = lights_random(sc, h.p, rng, (estimator & MIRT_RENDER_EVEN_LIGHTS) != 0);  // pdf.rs:85-91
-              else dir = onb_local(uvw, random_cosine_direction(rng));
-              const float c1 = dot(unit(dir), uvw.w);  // pdf.rs:25-32
-              const float cos_pdf = c1 <= 0.0f ? 0.0f : c1 / kPi;
-              pdf = 0.5f * lights_pdf_value(sc, h.p, dir) + 0.5f * cos_pdf;  // pdf.rs:81-83
+              dir = mixture_sample(ll, uvw, h.p, rng, (estimator & MIRT_RENDER_EVEN_LIGHTS) != 0, pdf);
             } else {
               dir = onb_local(uvw, random_cosine_direction(rng));
               const float c1 = dot(unit(dir), uvw.w);
@@ -1405,10 +1415,6 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
   {
     ConstArgs A = pinned(args);
     stage_media(A->sc.n_media, A->sc.media, A->sc.prims, sh.media);
-    if (A->sc.n_lights <= LDS_LIGHTS && A->sc.n_light_groups <= LDS_LIGHTS) {
-      if (threadIdx.x < A->sc.n_lights) sh.lights[threadIdx.x] = A->sc.lights[threadIdx.x];
-      if (threadIdx.x < A->sc.n_light_groups) sh.light_groups[threadIdx.x] = A->sc.light_groups[threadIdx.x];
-    }
     if (LDS_SCENE) {
       const RenderLds<true> lds(smem, A);
       const float4 *nodes = A->sc.nodes, *prims = A->sc.prims, *chain_ops = A->sc.chain_ops;
@@ -1424,13 +1430,16 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
         lds.prims[k] = prims[(k / PRIM_QUADS_LDS) * PRIM_QUADS + (k % PRIM_QUADS_LDS)];
       for (uint32_t k = threadIdx.x; k < n_chain_ops; k += THREADS) lds.ops[k] = chain_ops[k];
       for (uint32_t k = threadIdx.x; k < n_chains * 2u; k += THREADS) lds.chains[k] = chains[k];
-      if (A->lds_shading != 0) {
-        const float4* materials = reinterpret_cast<const float4*>(A->sc.materials);
-        const float4* textures = reinterpret_cast<const float4*>(A->sc.textures);
-        const uint32_t n_materials = A->sc.n_materials, n_texture_quads = A->sc.n_textures * 2u;
-        for (uint32_t k = threadIdx.x; k < n_materials; k += THREADS) lds.materials[k] = materials[k];
-        for (uint32_t k = threadIdx.x; k < n_texture_quads; k += THREADS) lds.textures[k] = textures[k];
-      }
+      const float4* materials = reinterpret_cast<const float4*>(A->sc.materials);
+      const float4* textures = reinterpret_cast<const float4*>(A->sc.textures);
+      const float4* lights = reinterpret_cast<const float4*>(A->sc.lights);
+      const uint2* groups = A->sc.light_groups;
+      const uint32_t n_materials = A->sc.n_materials, n_texture_quads = A->sc.n_textures * 2u;
+      const uint32_t n_light_quads = A->sc.n_lights * 2u, n_groups = A->sc.n_light_groups;
+      for (uint32_t k = threadIdx.x; k < n_materials; k += THREADS) lds.materials[k] = materials[k];
+      for (uint32_t k = threadIdx.x; k < n_texture_quads; k += THREADS) lds.textures[k] = textures[k];
+      for (uint32_t k = threadIdx.x; k < n_light_quads; k += THREADS) lds.lights[k] = lights[k];
+      for (uint32_t k = threadIdx.x; k < n_groups; k += THREADS) reinterpret_cast<uint2*>(lds.groups)[k] = groups[k];
     }
   }
 
@@ -1538,21 +1547,18 @@ RenderConfig plan_render(const DeviceScene& sc) {
   cfg.grid = N_REGIONS;
   // a stack entry per inner node on the path plus the pending sibling of the last one
   const int depth = (int)sc.bvh_height + 2;
+  // nodes, 48-byte primitive records, wrapper chains; then what shading looks up: materials, textures, lights
   const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * PRIM_QUADS_LDS * 16 +
-                             (size_t)sc.n_chain_ops * 16 + (size_t)sc.n_chains * 32;
-  // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes
-  const auto lds_total = [&](size_t table_bytes) {  // bookkeeping, tables, then the stacks on a row of their own
-    return SHARED_BYTES + (table_bytes + 255) / 256 * 256 + (size_t)depth * RENDER_THREADS * 2;
-  };
-  if (lds_total(scene_bytes) <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
+                             (size_t)sc.n_chain_ops * 16 + (size_t)sc.n_chains * 32 +
+                             (size_t)sc.n_materials * sizeof(DMaterial) + (size_t)sc.n_textures * sizeof(DTexture) +
+                             (size_t)sc.n_lights * sizeof(DLight) + ((size_t)sc.n_light_groups + 1) / 2 * 16;
+  // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes;
+  // bookkeeping, tables, then the stacks on a row of their own
+  const size_t lds_total = SHARED_BYTES + (scene_bytes + 255) / 256 * 256 + (size_t)depth * RENDER_THREADS * 2;
+  if (lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
     cfg.lds_scene = true;
     cfg.stack_depth = depth;
-    cfg.lds_bytes = lds_total(scene_bytes);
-    const size_t shading_bytes = (size_t)sc.n_materials * sizeof(DMaterial) + (size_t)sc.n_textures * sizeof(DTexture);
-    if (lds_total(scene_bytes + shading_bytes) <= LDS_BYTES_PER_CU && !std::getenv("MIRT_NO_LDS_SHADING")) {
-      cfg.lds_shading = true;
-      cfg.lds_bytes = lds_total(scene_bytes + shading_bytes);
-    }
+    cfg.lds_bytes = lds_total;
   } else {
     cfg.lds_scene = false;
     cfg.stack_depth = STACK_DEPTH;

@@ -633,7 +633,6 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.rgb_sum = job.rgb_sum;
   args.refill_min = cfg.refill_min;
   args.node_min = cfg.node_min;
-  args.lds_shading = cfg.lds_shading ? 1u : 0u;
   args.rays = job.rays;
   args.hit_type = job.hit_type;
   args.hit_object = job.hit_object;

@@ -204,15 +204,14 @@ constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
 // ---- launchers implemented in kernels.hip ------------------------------------
 // How the render kernel is launched for a scene: one 1024-thread block per region, with nodes, primitive
-// records and wrapper chains staged in LDS when they fit beside the block's traversal stacks, else read from
-// global memory.
+// records, wrapper chains, materials, textures and the light list staged in LDS when they fit beside the block's
+// traversal stacks, else read from global memory.
 struct RenderConfig {
   bool lds_scene;
   int block;
   int grid;
   int stack_depth;
   size_t lds_bytes;
-  bool lds_shading;     // materials and textures fit in LDS too
   uint32_t refill_min;  // a wave hands in finished rays and fetches new ones once this many lanes have none
   uint32_t node_min;    // a wave keeps stepping down the tree while this many of its lanes hold an inner node
 };
@@ -228,7 +227,6 @@ struct RenderArgs {
   WorkCounters* work;
   float* rgb_sum;
   uint32_t refill_min, node_min;
-  uint32_t lds_shading;  // materials and textures are staged in LDS behind the wrapper chains
   // Tracing caller-supplied rays instead of rendering (rays != nullptr): rc.total_paths rays come from `rays`,
   // each is walked once, and what ray g hit goes to hit_type[g], hit_object[g], hit_t[g].
   const mirt_ray* rays;
