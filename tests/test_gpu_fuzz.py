@@ -68,3 +68,90 @@ def test_random_sphere_fields_match_the_exhaustive_scan(scale, n, seed, builder,
     assert 0.2 < hit.mean() < 1.0
     assert np.array_equal(np.where(ti == 0xFFFFFFFF, 0xFFFFFFFF, oi), want_i)
     assert np.array_equal(t.view(np.uint32), want_t.view(np.uint32))
+
+
+def rect_scan(axis, a0, a1, b0, b1, k, o, d, t_min, t_max):
+    """XYRect / XZRect / YZRect::hit (objects.rs:196-228, 251-283, 325-357): axis 0 = xy (k on z), 1 = xz (k on y),
+    2 = yz (k on x); returns (accepted, t)."""
+    n, a, b = ((2, 0, 1), (1, 0, 2), (0, 1, 2))[axis]
+    with np.errstate(all="ignore"):
+        t = (k - o[:, n]) / d[:, n]
+        pa = o[:, a] + t * d[:, a]
+        pb = o[:, b] + t * d[:, b]
+    bad = (t < t_min) | (t > t_max) | (pa < a0) | (pa > a1) | (pb < b0) | (pb > b1) | np.isnan(t)
+    return ~bad, t
+
+
+def mixed_scan(prims, rays, t_min=F(0.001)):
+    """World::hit over a list of ("sphere", c, r) / ("rect", axis, a0, a1, b0, b1, k) / ("box", mn, mx) in order."""
+    o, d = rays[:, 0:3].astype(F), rays[:, 3:6].astype(F)
+    best_t = np.full(len(rays), np.inf, F)
+    best_i = np.full(len(rays), 0xFFFFFFFF, np.uint32)
+    for i, p in enumerate(prims):
+        if p[0] == "sphere":
+            bi, bt = scan(np.array([p[1]], F), np.array([p[2]], F), rays, t_min)   # one sphere, full range ...
+            ok = (bi == 0) & ~(bt > best_t)                                          # ... then the shrinking t_max
+            t = bt
+        elif p[0] == "rect":
+            ok, t = rect_scan(p[1], *[F(v) for v in p[2:7]], o, d, t_min, best_t)
+        else:
+            mn, mx = np.array(p[1], F), np.array(p[2], F)
+            closest = best_t.copy()
+            ok = np.zeros(len(rays), bool)
+            for axis, a, b, k in ((0, 0, 1, mx[2]), (0, 0, 1, mn[2]), (1, 0, 2, mn[1]), (1, 0, 2, mx[1]),
+                                  (2, 1, 2, mn[0]), (2, 1, 2, mx[0])):               # objects.rs:380-393, 396-436
+                hit, tt = rect_scan(axis, mn[a], mx[a], mn[b], mx[b], k, o, d, t_min, closest)
+                closest = np.where(hit, tt, closest)
+                ok |= hit
+            t = closest
+        best_t = np.where(ok, t, best_t)
+        best_i = np.where(ok, np.uint32(i), best_i)
+    return best_i, best_t
+
+
+@pytest.mark.parametrize("scale,seed", [(1.0, 11), (500.0, 12), (0.05, 13)])
+def test_random_mixed_scenes_match_the_exhaustive_scan(scale, seed):
+    """Spheres, rects of the three orientations and boxes in one World, rays also starting on rect planes and box faces."""
+    rng = np.random.default_rng(seed)
+    prims, spheres, rects, boxes = [], [], [], []
+    for i in range(900):
+        kind = rng.integers(0, 3)
+        c = rng.uniform(-10, 10, 3) * scale
+        if kind == 0:
+            r = float(np.exp(rng.normal(-0.5, 0.7)) * scale)
+            prims.append(("sphere", F(c), F(r)))
+            spheres.append(sphere(tuple(F(c)), float(F(r)), order=i, ti=0, oi=i))
+        elif kind == 1:
+            axis = int(rng.integers(0, 3))
+            ext = rng.uniform(0.2, 4.0, 2) * scale
+            a0, b0 = rng.uniform(-10, 10, 2) * scale
+            vals = [F(a0), F(a0 + ext[0]), F(b0), F(b0 + ext[1]), F(c[2])]
+            prims.append(("rect", axis, *vals))
+            rects.append(R.Rect(R.PrimHeader(0, 0, i, 0, i, 0), axis, *[float(v) for v in vals]))
+        else:
+            ext = rng.uniform(0.2, 3.0, 3) * scale
+            mn, mx = F(c), F(c + ext)
+            prims.append(("box", mn, mx))
+            boxes.append(R.Box(R.PrimHeader(0, 0, i, 0, i, 0), (C.c_float * 3)(*mn), (C.c_float * 3)(*mx)))
+    m = 12000
+    rays = np.zeros((m, 7), F)
+    rays[:, 0:3] = rng.uniform(-13, 13, (m, 3)) * scale
+    rays[:, 3:6] = rng.normal(size=(m, 3)) * rng.uniform(0.05, 20.0, (m, 1))
+    k = 0
+    for p in prims:                                   # origins on faces: the next hit must not be the face left
+        if p[0] == "box" and k < 2000:
+            mn, mx = p[1], p[2]
+            rays[k, 0:3] = [(mn[0] + mx[0]) / 2, mx[1], (mn[2] + mx[2]) / 2]          # centre of the top face
+            k += 1
+    ctx = Ctx()
+    try:
+        scene = ctx.upload(spheres=spheres, rects=rects, boxes=boxes)
+        ti, oi, t = ctx.trace(scene, rays)
+    finally:
+        ctx.close()
+    want_i, want_t = mixed_scan(prims, rays)
+    assert 0.3 < (want_i != 0xFFFFFFFF).mean() < 1.0
+    got_i = np.where(ti == 0xFFFFFFFF, 0xFFFFFFFF, oi)
+    bad = np.nonzero(got_i != want_i)[0]
+    assert bad.size == 0, (bad[:5], got_i[bad[:5]], want_i[bad[:5]], t[bad[:5]], want_t[bad[:5]])
+    assert np.array_equal(t.view(np.uint32), want_t.view(np.uint32))
