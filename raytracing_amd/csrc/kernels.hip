@@ -1150,7 +1150,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   }
 }
 
-// Shades the region's four queues (renderer.rs:141-212): constant media get their chance, the material
+// Shades the region's queues (renderer.rs:141-212): constant media get their chance, the material
 // scatters or ends the path, survivors are packed into the first slots of the region's other buffer.
 template <bool COUNT, bool LDS_SCENE>
 __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_arg, bool odd) {
@@ -1187,7 +1187,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
   // what stays in its queue and appends the rest (written back with the medium hit) to the queue of the
   // medium's material; the second shades those.  Every wave then runs one material's code with full lanes.
   for (uint32_t pass = 0; pass < 2u; ++pass) {
-    // The entries of the four queues are cut into batches of 64, numbered queue after queue; a wave takes the
+    // The entries of the queues are cut into batches of 64, numbered queue after queue; a wave takes the
     // next batch whenever it has finished one, so no wave is left with the expensive ones.
     uint32_t first[N_QUEUES], count[N_QUEUES], last_batch[N_QUEUES];
     uint32_t n_batches = 0;
@@ -1486,7 +1486,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
     __syncthreads();  // the new rays are visible to the whole block
     walk_rays<COUNT, LDS_SCENE>(args, lds_address, odd, total, &work, &segments);
-    __syncthreads();  // every live slot carries its surface hit and sits in one of the four queues
+    __syncthreads();  // every walked ray's record, surface hit included, sits in one of the region's queues
     if (COUNT) ts = clock64();
     if (tracing) report_hits<LDS_SCENE>(args, lds_address, odd);
     else shade_queues<COUNT, LDS_SCENE>(args, lds_address, odd);

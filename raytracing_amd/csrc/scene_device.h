@@ -131,8 +131,8 @@ struct DeviceScene {
 
 // ---- the path pool ----------------------------------------------------------------
 // The pool is split into N_REGIONS equal regions of consecutive slots, one per block of the render kernel.
-// A region is private to its block: two buffers of path records (this round's and the next one's) and four
-// material queues of slot numbers.  The only thing the blocks share is the counter new paths are numbered from.
+// A region is private to its block: two buffers of path records (this round's and the next one's) and N_QUEUES
+// shading queues of path records.  The only thing the blocks share is the counter new paths are numbered from.
 constexpr uint32_t N_REGIONS = 256;
 constexpr uint32_t POOL_GRANULE = N_REGIONS * 64;  // a region is a whole number of waves
 
@@ -195,8 +195,8 @@ struct RenderConst {
 //   r0 = origin.xyz, time
 //   r1 = direction.xyz, bits(pixel = y*width + x, y up)
 //   r2 = throughput.rgb, bits(sample index << 8 | bounce)
-//   r3 = t of the closest surface, bits(hit ref), bits(side of a box hit), -     (the only part the walk writes
-//        for a surviving path)
+//   r3 = t of the closest surface, bits(hit ref), bits(side of a box hit), -     (only in the copy the walk puts
+//        into a shading queue; the two record buffers carry r0..r2)
 // Shading queue q of region s holds whole path records (the walk moves a finished ray's record there, hit
 // included) at queues[4 * (s * N_QUEUES + q) * region_cap ...]: shading reads a queue front to back.
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
