@@ -1082,7 +1082,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       // Rays that are done leave their hit in the record and their slot in the queue of the material
       // hit.  Lane q reserves queue q's entries for the whole wave in the block's LDS counters; the lane after
       // those takes the wave's new rays off the region's list.
-      const int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(w.best_material));
+      int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(w.best_material));
+      if (q == QUEUE_LAMBERTIAN && ref_tag(w.best_ref) >= TAG_RECT) q = QUEUE_LAMBERTIAN_FLAT;
       unsigned long long mq = 0ull;  // the lanes handing in to the same queue as this one
       uint32_t cnt = 0;
 #pragma unroll

@@ -155,9 +155,12 @@ struct WorkCounters {
 };
 
 // Hits are shaded queue by queue so that a wave runs one material's code: Lambertian surfaces of one colour,
-// metal, glass, what ends the path (lights, Isotropic, misses), Lambertian surfaces with a texture to evaluate.
+// metal, glass, what ends the path (lights, Isotropic, misses), Lambertian surfaces with a texture to evaluate;
+// single-colour Lambertian hits are split once more by the primitive hit (spheres and media / rects and boxes: the
+// hit records are worked out by different code, and the survivors of one queue start near each other, which keeps
+// the next walk's waves on the same kind of primitive).  The material word names queues 0..4.
 constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3,
-              QUEUE_LAMBERTIAN_TEXTURED = 4, N_QUEUES = 5;
+              QUEUE_LAMBERTIAN_TEXTURED = 4, QUEUE_LAMBERTIAN_FLAT = 5, N_QUEUES = 6;
 
 // Division of a 32-bit number by a divisor fixed for the whole launch: a multiply-high and two shifts in
 // place of the long sequence a division compiles to (Granlund & Montgomery, unsigned case).
