@@ -14,6 +14,7 @@
 // the reference.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1580,12 +1581,18 @@ RenderConfig plan_render(const DeviceScene& sc) {
 
 template <bool COUNT, bool LDS_SCENE>
 static hipError_t launch_render_as(const RenderArgs* args, const RenderConfig& cfg, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<COUNT, LDS_SCENE>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU);
+  // the larger dynamic-LDS limit is a property of the function on one device: set once for each device used
+  // (a context serves one call at a time, but contexts on several devices may call from several threads)
+  static std::atomic<unsigned long long> devices_set{0};
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (device & 63);
+  if (device >= 64 || !(devices_set.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render<COUNT, LDS_SCENE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (device < 64) devices_set.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((k_render<COUNT, LDS_SCENE>), dim3(cfg.grid), dim3(RENDER_THREADS), cfg.lds_bytes, stream, args);
   return hipGetLastError();
