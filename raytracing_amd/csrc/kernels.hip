@@ -332,6 +332,7 @@ struct Walk {
   V3 inv;
   float best_t;
   uint32_t best_ref, best_order, best_material, best_face, cur, sp;
+  float t_lo;  // the walk looks for hits from here on (renderer.rs:150's t_min, or where the last stretch ended)
 };
 
 __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root) {
@@ -345,6 +346,7 @@ __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root)
   w.best_face = 0;
   w.cur = root;
   w.sp = 0;
+  w.t_lo = kTMin;
 }
 
 // One step down the tree (w.cur must be an inner node): both child boxes are tested, the nearer one that
@@ -980,6 +982,7 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
   const FastDiv by_groups{A->rc.by_groups.m, A->rc.by_groups.sh1, A->rc.by_groups.sh2};
   const FastDiv by_band{A->rc.by_band.m, A->rc.by_band.sh1, A->rc.by_band.sh2};
   const uint32_t strata = A->rc.strata;
+  const bool chunked = A->chunk_len > 0.0f;
   const FastDiv by_strata{A->rc.by_strata.m, A->rc.by_strata.sh1, A->rc.by_strata.sh2};
   const FastDiv by_cells{A->rc.by_cells.m, A->rc.by_cells.sh1, A->rc.by_cells.sh2};
   // path number = pass * pixels + place in the pass; the one long division is done once for the block
@@ -1032,6 +1035,7 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
     cur[4 * i] = make_float4(o.x, o.y, o.z, time);
     cur[4 * i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
     cur[4 * i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
+    if (chunked) cur[4 * i + 3] = make_float4(kTMin, 0.0f, 0.0f, 0.0f);  // where its first stretch starts
   }
 }
 
@@ -1060,6 +1064,9 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   const uint32_t root = RC::encode(A->sc.root_ref);
   const uint32_t refill_min = A->refill_min, node_min = A->node_min;
+  const float chunk_len = LDS_SCENE ? 0.0f : A->chunk_len;
+  const V3 root_lo = v3(A->sc.root_lo[0], A->sc.root_lo[1], A->sc.root_lo[2]);
+  const V3 root_hi = v3(A->sc.root_hi[0], A->sc.root_hi[1], A->sc.root_hi[2]);
   Work work{};
   uint32_t segments = 0;
   long long ts = 0;
@@ -1085,6 +1092,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       // those takes the wave's new rays off the region's list.
       int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(w.best_material));
       if (q == QUEUE_LAMBERTIAN && ref_tag(w.best_ref) >= TAG_RECT) q = QUEUE_LAMBERTIAN_FLAT;
+      // nothing found in this stretch and the ray goes on (best_t is still where the stretch ends): next round
+      if (!LDS_SCENE && done && w.best_ref == REF_NONE && w.best_t < kInf) q = QUEUE_CONTINUE;
       unsigned long long mq = 0ull;  // the lanes handing in to the same queue as this one
       uint32_t cnt = 0;
 #pragma unroll
@@ -1110,7 +1119,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         out[2] = state;
         out[3] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), 0.0f);
         slot = NO_SLOT;
-        ++segments;
+        if (LDS_SCENE || q != QUEUE_CONTINUE) ++segments;
       }
       if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_WRITE] += now - ts; ts = now; }
       // (the lanes refilled together get consecutive slots: new camera paths of one pixel tile, which walk
@@ -1126,6 +1135,18 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
           walk_begin(w, r, root);
+          if (!LDS_SCENE && chunk_len > 0.0f) {
+            // This round's stretch: from where the last one ended, chunk_len further; if the ray has left the
+            // scene's bounds by then this is its last stretch.  (best_t stays at the stretch's end until a hit
+            // is found, which the tests accept up to and including that distance.)
+            w.t_lo = cur[4 * (size_t)slot + 3].x;
+            // (the second term keeps a stretch from rounding to nothing far along a ray)
+            const float t_hi = fmaxf(w.t_lo + chunk_len * __builtin_amdgcn_rsqf(len2(r.d)), w.t_lo * 1.0009765625f);
+            float t_enter;
+            // how far the ray stays inside the (padded) bounds: slab() with the far end open reports entry <= exit
+            const bool inside = slab(root_lo, root_hi, r.o, w.inv, t_hi, kInf, t_enter);
+            w.best_t = inside ? t_hi : kInf;
+          }
         }
       }
       if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
@@ -1133,14 +1154,14 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
     if (COUNT) ts = clock64();
     while (!(w.cur & RC::LEAF)) {
       if (COUNT) { ++work.nodes; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_nodes; }
-      node_step<LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+      node_step<LDS_SCENE>(w, tb, LDS_SCENE ? kTMin : w.t_lo, stack, THREADS);
       // the last few lanes still on their way down do not keep the others waiting
       if ((uint32_t)__popcll(__ballot(!(w.cur & RC::LEAF))) < node_min) break;
     }
     if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_NODES] += now - ts; ts = now; }
     if ((w.cur & RC::LEAF) && w.cur != RC::NONE) {
       if (COUNT) { ++work.prims; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_prims; }
-      prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+      prim_step<PSTRIDE, LDS_SCENE>(w, tb, LDS_SCENE ? kTMin : w.t_lo, stack, THREADS);
     }
     if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - ts;
   }
@@ -1181,6 +1202,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
          {A->rc.by_width.m, A->rc.by_width.sh1, A->rc.by_width.sh2}};
   const uint32_t cap = A->rc.region_cap;
   const uint32_t estimator = A->rc.estimator;
+  const bool chunked = !LDS_SCENE && A->chunk_len > 0.0f;
   float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
   float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   float* const rgb_sum = A->rgb_sum;
@@ -1216,6 +1238,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       Ray nr;
       V3 beta = v3(0.0f, 0.0f, 0.0f);
       uint32_t pixel = 0, sample = 0, bounce = 0;
+      float next_lo = kTMin;  // where the walk of the surviving ray starts looking
       if (e < n_q) {
         const float4* const rec = entries + 4 * (size_t)e;
         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
@@ -1228,7 +1251,8 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         float t = r3.x;
         uint32_t ref = __float_as_uint(r3.y);
         bool deferred = false;
-        if (n_media != 0 && pass == 0) {  // the walk found the closest surface; the media in front of it get their chance now
+        const bool goes_on = !LDS_SCENE && q == (uint32_t)QUEUE_CONTINUE;  // t: where its next stretch starts
+        if (n_media != 0 && pass == 0 && !goes_on) {  // the walk found the closest surface; the media in front of it get their chance now
           uint32_t material = 0;
           const uint32_t surface = ref;
           Rng mrng = rng_begin(pixel, sample, bounce, STAGE_MEDIA, rc.key0, rc.key1);
@@ -1246,7 +1270,12 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         }
 
         V3 term = v3(0.0f, 0.0f, 0.0f);  // radiance that ends the path
-        if (deferred) {
+        if (goes_on) {  // back into the pool as it is
+          nr = r;
+          next_lo = t;
+          bounce -= 1u;  // (the survivor's record counts one bounce more than `bounce`)
+          alive = true;
+        } else if (deferred) {
           beta = v3(0.0f, 0.0f, 0.0f);  // nothing to add to the image from here
         } else if (ref == REF_NONE) {
           term = v3(rc.background[0], rc.background[1], rc.background[2]);  // renderer.rs:187-189
@@ -1297,7 +1326,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
           // MIRT_MAT_ISOTROPIC: no scatter, no emission
         }
         // The child call at depth 0 returns black without tracing (renderer.rs:147-149).
-        if (alive && bounce + 1 >= rc.max_depth) alive = false;
+        if (alive && !goes_on && bounce + 1 >= rc.max_depth) alive = false;
         if (!alive) {
           // beta * term is the path's whole contribution; it is added even when
           // term is zero if beta is NaN/inf so a poisoned sample blackens its
@@ -1320,6 +1349,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         next[4 * to] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
         next[4 * to + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
         next[4 * to + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
+        if (chunked) next[4 * to + 3] = make_float4(next_lo, 0.0f, 0.0f, 0.0f);
       }
     }
     if (n_media == 0 || pass == 1u) break;

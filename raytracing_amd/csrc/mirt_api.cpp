@@ -376,6 +376,12 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
 
   // ---- acceleration structure ----------------------------------------------------
   s.n_prims = build.size();
+  for (int a = 0; a < 3; ++a) { s.view.root_lo[a] = 0.0f; s.view.root_hi[a] = 0.0f; }
+  for (size_t k = 0; k < build.size(); ++k)
+    for (int a = 0; a < 3; ++a) {
+      if (k == 0 || build[k].mn[a] < s.view.root_lo[a]) s.view.root_lo[a] = build[k].mn[a];
+      if (k == 0 || build[k].mx[a] > s.view.root_hi[a]) s.view.root_hi[a] = build[k].mx[a];
+    }
   uint32_t leaf_max = LEAF_MAX_PRIMS;
   if (const char* e = std::getenv("MIRT_LEAF_MAX")) {  // tuning aid
     const long v = std::strtol(e, nullptr, 10);
@@ -632,6 +638,19 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.work = ctx->work.as<WorkCounters>();
   args.rgb_sum = job.rgb_sum;
   args.refill_min = cfg.refill_min;
+  args.chunk_len = 0.0f;
+  // Large scenes (from 2^18 primitives): rays are walked a thirty-second of the bounds' diagonal per round.  The few
+  // rays that graze such a scene for thousands of steps then no longer hold up every round (1 M spheres: +57 %,
+  // 10 M: +95 %); smaller scenes have no such rays and only pay for the extra rounds (6.5 k spheres: -18 %).
+  if (!cfg.lds_scene && !job.rays && (scene->n_prims >= (1u << 18) || std::getenv("MIRT_CHUNKS"))) {
+    long chunks = 32;
+    if (const char* e = std::getenv("MIRT_CHUNKS")) chunks = std::strtol(e, nullptr, 10);  // tuning aid; 0 = whole rays
+    const DeviceScene& sv = scene->view;
+    const double dx = (double)sv.root_hi[0] - sv.root_lo[0], dy = (double)sv.root_hi[1] - sv.root_lo[1],
+                 dz = (double)sv.root_hi[2] - sv.root_lo[2];
+    const double diagonal = std::sqrt(dx * dx + dy * dy + dz * dz);
+    if (chunks > 0 && diagonal > 0.0 && std::isfinite(diagonal)) args.chunk_len = (float)(diagonal / (double)chunks);
+  }
   args.node_min = cfg.node_min;
   args.rays = job.rays;
   args.hit_type = job.hit_type;

@@ -122,6 +122,8 @@ struct DeviceScene {
   const DImage* images;
   const uint8_t* image_data;
 
+  float root_lo[3], root_hi[3];  // bounds of everything in the tree
+
   uint32_t lights_mode;
   uint32_t n_lights;
   uint32_t n_light_groups;
@@ -159,8 +161,10 @@ struct WorkCounters {
 // single-colour Lambertian hits are split once more by the primitive hit (spheres and media / rects and boxes: the
 // hit records are worked out by different code, and the survivors of one queue start near each other, which keeps
 // the next walk's waves on the same kind of primitive).  The material word names queues 0..4.
+// QUEUE_CONTINUE holds rays of a large scene that found nothing in the stretch walked this round: they go back
+// into the pool unshaded and walk their next stretch in the next round.
 constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3,
-              QUEUE_LAMBERTIAN_TEXTURED = 4, QUEUE_LAMBERTIAN_FLAT = 5, N_QUEUES = 6;
+              QUEUE_LAMBERTIAN_TEXTURED = 4, QUEUE_LAMBERTIAN_FLAT = 5, QUEUE_CONTINUE = 6, N_QUEUES = 7;
 
 // Division of a 32-bit number by a divisor fixed for the whole launch: a multiply-high and two shifts in
 // place of the long sequence a division compiles to (Granlund & Montgomery, unsigned case).
@@ -230,6 +234,9 @@ struct RenderArgs {
   WorkCounters* work;
   float* rgb_sum;
   uint32_t refill_min, node_min;
+  // Scenes walked from global memory: a ray is walked this far (world distance) per round, so that the few rays
+  // that graze a large scene for thousands of steps do not hold up the round for everyone; 0 = to the end.
+  float chunk_len;
   // Tracing caller-supplied rays instead of rendering (rays != nullptr): rc.total_paths rays come from `rays`,
   // each is walked once, and what ray g hit goes to hit_type[g], hit_object[g], hit_t[g].
   const mirt_ray* rays;

@@ -235,3 +235,28 @@ def test_device_built_tree_finds_the_same_hits(name, lo, hi, monkeypatch):
     finally:
         g.close()
         o.close()
+
+
+@pytest.mark.parametrize("chunks", ["7", "64", "1000"])
+def test_rays_walked_in_stretches_find_the_same_hits(chunks, monkeypatch):
+    """Large scenes walk a ray a stretch of the scene's diagonal per round and carry it over if nothing was hit
+    (forced here on the 6.5 k-sphere scene): the closest hit is the first stretch with a hit, so the image is the one
+    whole-ray walks give, and the oracle's."""
+    name, w, h, spp = "synthetic_bvh:40", 96, 54, 4
+    g, o = R.ExampleScene(name), O.Scene(name)
+    try:
+        monkeypatch.setenv("MIRT_CHUNKS", "0")
+        whole, whole_sums, st0 = g.render(w, h, spp, seed=21, flags=R.MIRT_RENDER_COUNT_WORK)
+        monkeypatch.setenv("MIRT_CHUNKS", chunks)
+        rgb, sums, st = g.render(w, h, spp, seed=21, flags=R.MIRT_RENDER_COUNT_WORK)
+        orgb, osums, oseg = o.render(w, h, spp, seed=21)
+    finally:
+        g.close()
+        o.close()
+    assert st["segments"] == st0["segments"]
+    assert st["iterations"] > st0["iterations"]          # more rounds: rays were carried over
+    ok = np.isfinite(sums) & np.isfinite(whole_sums)
+    assert np.array_equal(np.isfinite(sums), np.isfinite(whole_sums))
+    assert np.allclose(sums[ok], whole_sums[ok], rtol=1e-4, atol=1e-5)
+    assert float(O.psnr(rgb, orgb)) > 55.0
+    assert abs(st["segments"] - oseg) <= max(8, oseg // 20000)
