@@ -93,12 +93,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MIRT_BENCH_REHEARSE=1: every rank on GPU 0 over gloo, to walk through the N > 1 code on a one-GPU box
+    rehearse = world > 1 and os.environ.get("MIRT_BENCH_REHEARSE") == "1"
+    device_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    scene = R.ExampleScene(a.scene, scene_seed=1, device=local_rank)
+    scene = R.ExampleScene(a.scene, scene_seed=1, device=device_index)
     depth = a.depth or scene.depth
     aspect = a.width / a.height
     # sample-range sharding: rank r renders samples [first, first + count) of every pixel
@@ -118,7 +124,10 @@ def main():
                                          seed=a.seed, first_sample=first, path_pool=a.pool, flags=step_flags,
                                          stream=stream)
         if world > 1:
-            dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
+            if rehearse:  # gloo has no reduce for device tensors
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            else:
+                dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
             scene.resolve(sums.data_ptr(), a.width, a.height, total_spp, rgb.data_ptr(), stream=stream)
         return st
@@ -146,7 +155,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -1,0 +1,33 @@
+"""bench.py's N > 1 code walked through on one GPU: two ranks share GPU 0 and exchange over gloo
+(MIRT_BENCH_REHEARSE=1); the real run uses one GPU per rank over RCCL.  Checks the contract of the JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_prints_one_whole_job_line():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MIRT_BENCH_REHEARSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "16",
+           "--width", "640", "--height", "360"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["workload"] == "final_scene 640x360, 32 spp, depth 5"      # 16 spp on each of two ranks
+    assert d["unit"] == "Msamples/s" and d["value"] > 0 and d["higher_is_better"] is True
+    assert abs(d["value"] - 640 * 360 * 32 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
