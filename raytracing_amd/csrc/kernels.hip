@@ -323,6 +323,7 @@ struct RefCode {
   }
 };
 constexpr uint32_t COMPACT_MAX_PRIMS = 4096, COMPACT_MAX_NODES = 32768;
+constexpr uint32_t SCAN_MAX_PRIMS = 12;  // scenes up to this size are scanned without the tree
 
 // State of one ray's walk through the tree: the ray, the closest hit so far (smallest t, and of equal t
 // the primitive with the higher `order`, which is what the reference's exhaustive scan returns) and the
@@ -1173,6 +1174,90 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   }
 }
 
+// The walk of a scene of a handful of primitives: no tree.  A wave takes 64 rays and tests them against one
+// primitive after the other, every lane the same primitive at the same time, so a wave never runs the code of
+// two kinds of primitive at once (with a tree over 8 primitives a ray tests 5 of them anyway, each lane another).
+// Closest hit, equal t to the higher order rank: the same answer as the tree walk.
+template <bool COUNT>
+__device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg, bool odd, uint32_t total, Work* work_out,
+                                       uint32_t* segments_out) {
+  float4* const smem = lds_base(lds_arg);
+  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  ConstArgs A = pinned(args);
+  odd = uniform(odd) != 0;
+  total = uniform(total);
+  const RenderLds<true> lds(smem, A);
+  const SceneTables tb = lds.tables(A);
+  const uint32_t lane = lane_id();
+  const uint32_t cap = A->rc.region_cap;
+  const uint32_t n_prims = A->sc.n_prims;
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)blockIdx.x * cap;
+  float4* const region_queues = A->queues + 4 * (size_t)blockIdx.x * N_QUEUES * cap;
+  uint32_t segments = 0;
+  long long ts = 0;
+  Work work{};
+  for (;;) {
+    if (COUNT) ts = clock64();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&sh.next_work, 64u);
+    base = uniform(base);
+    if (base >= total) break;
+    const uint32_t entry = base + lane;
+    const bool live = entry < total;
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, state = r0;
+    if (live) { r0 = cur[4 * (size_t)entry]; r1 = cur[4 * (size_t)entry + 1]; state = cur[4 * (size_t)entry + 2]; }
+    Ray r;
+    r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
+    float best_t = kInf;
+    uint32_t best_ref = REF_NONE, best_order = 0, best_material = 0, best_face = 0;
+    if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_LOAD] += now - ts; ts = now; }
+    for (uint32_t k = 0; k < n_prims; ++k) {
+      float t;
+      uint32_t tag, order, material, face = 0;
+      if (live && record_t<(int)PRIM_QUADS_LDS>(tb, k, r, kTMin, best_t, t, tag, order, material, face)) {
+        if (t < best_t || best_ref == REF_NONE || order > best_order) {  // equal t: the later one in the reference's order
+          best_t = t; best_ref = make_leaf(tag, k); best_material = material; best_order = order; best_face = face;
+        }
+      }
+    }
+    if (COUNT) {
+      const long long now = clock64();
+      work.cycles[MIRT_PHASE_PRIMS] += now - ts; ts = now;
+      if (live) work.prims += n_prims;
+      if (lane == 0) work.wave_prims += n_prims;
+    }
+    int q = !live ? -1 : (best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(best_material));
+    if (q == QUEUE_LAMBERTIAN && ref_tag(best_ref) >= TAG_RECT) q = QUEUE_LAMBERTIAN_FLAT;
+    unsigned long long mq = 0ull;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < N_QUEUES; ++k) {
+      const unsigned long long m = __ballot(q == k);
+      if (q == k) mq = m;
+      if (lane == (uint32_t)k) cnt = (uint32_t)__popcll(m);
+    }
+    uint32_t got = 0;
+    if (lane < (uint32_t)N_QUEUES && cnt) got = atomicAdd(&sh.queue_n[lane], cnt);
+    const uint32_t bq = __shfl(got, q < 0 ? 0 : q);
+    if (live) {
+      const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+      float4* const out = region_queues + 4 * ((size_t)q * cap + pos);
+      out[0] = r0;
+      out[1] = r1;
+      out[2] = state;
+      out[3] = make_float4(best_t, __uint_as_float(best_ref), __uint_as_float(best_face), 0.0f);
+      ++segments;
+    }
+    if (COUNT) work.cycles[MIRT_PHASE_WRITE] += clock64() - ts;
+  }
+  if (COUNT) {
+    work_out->prims += work.prims;
+    work_out->wave_prims += work.wave_prims;
+    for (int k = 0; k < MIRT_PHASE_COUNT; ++k) work_out->cycles[k] += work.cycles[k];
+    *segments_out += segments;
+  }
+}
+
 // Shades the region's queues (renderer.rs:141-212): constant media get their chance, the material
 // scatters or ends the path, survivors are packed into the first slots of the region's other buffer.
 template <bool COUNT, bool LDS_SCENE>
@@ -1476,6 +1561,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
   }
 
   const bool tracing = pinned(args)->rays != nullptr;  // caller-supplied rays instead of camera paths
+  const bool small_scene = pinned(args)->sc.n_prims <= SCAN_MAX_PRIMS;  // tested one primitive after the other
   Work work{};
   long long k_begin = 0, ts = 0;
   if (COUNT) k_begin = clock64();
@@ -1517,7 +1603,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     else start_paths<COUNT>(args, odd, n_surv, n_fresh, ((uint64_t)sh.first_new_hi << 32) | sh.first_new_lo);
     if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
     __syncthreads();  // the new rays are visible to the whole block
-    walk_rays<COUNT, LDS_SCENE>(args, lds_address, odd, total, &work, &segments);
+    if (LDS_SCENE && small_scene) scan_rays<COUNT>(args, lds_address, odd, total, &work, &segments);
+    else walk_rays<COUNT, LDS_SCENE>(args, lds_address, odd, total, &work, &segments);
     __syncthreads();  // every walked ray's record, surface hit included, sits in one of the region's queues
     if (COUNT) ts = clock64();
     if (tracing) report_hits<LDS_SCENE>(args, lds_address, odd);
