@@ -171,12 +171,11 @@ struct Builder {
 
 }  // namespace
 
-BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t leaf_max) {
+BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t leaf_max, float step_cost) {
   BuiltBvh out;
   if (prims.empty()) return out;
   out.nodes.reserve(prims.size());
-  float step_cost = 1.0f;
-  if (const char* e = std::getenv("MIRT_STEP_COST")) step_cost = (float)std::atof(e);  // tuning aid
+  if (const char* e = std::getenv("MIRT_STEP_COST")) step_cost *= (float)std::atof(e);  // tuning aid
   Builder b{prims, out.nodes, std::max(1u, std::min(leaf_max, 8u)), step_cost};
   const Child root = b.build(0, prims.size(), max_height + 1);
   out.root_ref = root.ref;

@@ -39,6 +39,8 @@ struct BuiltBvh {
 // max_height: the traversal stack holds one entry per inner node on the
 // current path, so the tree is kept no taller than this (falls back to
 // balanced median splits when the budget gets tight).
-BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t leaf_max);
+// step_cost: what one more step down the tree costs, in primitive tests; above 1 the build keeps larger leaves
+// (a smaller tree).
+BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t leaf_max, float step_cost = 1.0f);
 
 }  // namespace mirt

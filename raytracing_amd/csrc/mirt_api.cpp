@@ -412,6 +412,28 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     s.bvh_height = g.height;
   } else {
     BuiltBvh bvh = build_bvh(build, STACK_DEPTH - 2, leaf_max);
+    // A scene that just misses the render kernel's LDS budget would be walked from global memory at three quarters
+    // of the speed: larger leaves (up to 8, a dearer tree step in the builder's cost) make a smaller tree, which is
+    // the better trade then.
+    const auto fits_lds = [&](const BuiltBvh& b) {
+      DeviceScene probe{};
+      probe.n_nodes = (uint32_t)b.nodes.size();
+      probe.bvh_height = b.height;
+      probe.n_prims = (uint32_t)build.size();
+      probe.n_chain_ops = d.n_chain_ops;
+      probe.n_chains = d.n_chains;
+      probe.n_materials = d.n_materials;
+      probe.n_textures = d.n_textures;
+      probe.n_lights = d.n_lights;
+      probe.n_light_groups = d.n_light_groups;
+      return plan_render(probe).lds_scene;
+    };
+    const bool retry = !std::getenv("MIRT_NO_LDS_RETRY");  // measurement aid
+    for (float step_cost = 2.0f; retry && step_cost <= 4.0f && build.size() <= 4096 && !fits_lds(bvh); step_cost *= 2.0f) {
+      std::vector<BuildPrim> order = build;  // (the builder leaves the primitives in the order of its tree)
+      BuiltBvh smaller = build_bvh(order, STACK_DEPTH - 2, 8, step_cost);
+      if (fits_lds(smaller)) { bvh = std::move(smaller); build.swap(order); }  // (a much coarser tree would not pay)
+    }
     MIRT_HIP(ctx, upload(s.nodes, bvh.nodes));
     root_ref = bvh.root_ref;
     n_nodes = (uint32_t)bvh.nodes.size();

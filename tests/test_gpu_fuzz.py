@@ -39,7 +39,7 @@ def scan(centers, radii, rays, t_min=F(0.001)):
 
 
 @pytest.mark.parametrize("scale,n,seed,builder", [(1e-2, 300, 1, "host"), (1.0, 1500, 2, "host"), (1e3, 1500, 3, "host"),
-                                                  (1.0, 5000, 4, "host"), (1.0, 1500, 5, "device"),
+                                                  (1.0, 5000, 4, "host"), (1.0, 2000, 7, "host"), (1.0, 1500, 5, "device"),
                                                   (1e3, 5000, 6, "device")])
 def test_random_sphere_fields_match_the_exhaustive_scan(scale, n, seed, builder, monkeypatch):
     monkeypatch.setenv("MIRT_BVH_BUILDER", builder)   # host: surface-area tree; device: Morton-order tree
