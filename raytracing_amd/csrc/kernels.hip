@@ -1142,11 +1142,14 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
             // is found, which the tests accept up to and including that distance.)
             w.t_lo = cur[4 * (size_t)slot + 3].x;
             // (the second term keeps a stretch from rounding to nothing far along a ray)
-            const float t_hi = fmaxf(w.t_lo + chunk_len * __builtin_amdgcn_rsqf(len2(r.d)), w.t_lo * 1.0009765625f);
+            const float d2 = len2(r.d);
+            const float t_hi = fmaxf(w.t_lo + chunk_len * __builtin_amdgcn_rsqf(d2), w.t_lo * 1.0009765625f);
             float t_enter;
             // how far the ray stays inside the (padded) bounds: slab() with the far end open reports entry <= exit
             const bool inside = slab(root_lo, root_hi, r.o, w.inv, t_hi, kInf, t_enter);
-            w.best_t = inside ? t_hi : kInf;
+            // (a ray without a proper direction or origin is walked in one go: it has no stretch that ever ends)
+            const bool proper = d2 > 0.0f && d2 < kInf && fabsf(r.o.x) < kInf && fabsf(r.o.y) < kInf && fabsf(r.o.z) < kInf;
+            w.best_t = inside && proper && t_hi < kInf ? t_hi : kInf;
           }
         }
       }
