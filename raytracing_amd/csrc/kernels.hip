@@ -1091,7 +1091,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       // Rays that are done leave their hit in the record and their slot in the queue of the material
       // hit.  Lane q reserves queue q's entries for the whole wave in the block's LDS counters; the lane after
       // those takes the wave's new rays off the region's list.
-      int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(w.best_material));
+      int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_MISS : queue_of(w.best_material));
       if (q == QUEUE_LAMBERTIAN && ref_tag(w.best_ref) >= TAG_RECT) q = QUEUE_LAMBERTIAN_FLAT;
       // nothing found in this stretch and the ray goes on (best_t is still where the stretch ends): next round
       if (!LDS_SCENE && done && w.best_ref == REF_NONE && w.best_t < kInf) q = QUEUE_CONTINUE;
@@ -1229,7 +1229,7 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
       if (live) work.prims += n_prims;
       if (lane == 0) work.wave_prims += n_prims;
     }
-    int q = !live ? -1 : (best_ref == REF_NONE ? QUEUE_TERMINATE : queue_of(best_material));
+    int q = !live ? -1 : (best_ref == REF_NONE ? QUEUE_MISS : queue_of(best_material));
     if (q == QUEUE_LAMBERTIAN && ref_tag(best_ref) >= TAG_RECT) q = QUEUE_LAMBERTIAN_FLAT;
     unsigned long long mq = 0ull;
     uint32_t cnt = 0;

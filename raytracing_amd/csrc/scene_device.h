@@ -162,9 +162,11 @@ struct WorkCounters {
 // hit records are worked out by different code, and the survivors of one queue start near each other, which keeps
 // the next walk's waves on the same kind of primitive).  The material word names queues 0..4.
 // QUEUE_CONTINUE holds rays of a large scene that found nothing in the stretch walked this round: they go back
-// into the pool unshaded and walk their next stretch in the next round.
+// into the pool unshaded and walk their next stretch in the next round.  QUEUE_MISS: rays that hit nothing (only
+// the media and the background are left for them; apart from the surfaces that end a path in QUEUE_TERMINATE).
 constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3,
-              QUEUE_LAMBERTIAN_TEXTURED = 4, QUEUE_LAMBERTIAN_FLAT = 5, QUEUE_CONTINUE = 6, N_QUEUES = 7;
+              QUEUE_LAMBERTIAN_TEXTURED = 4, QUEUE_LAMBERTIAN_FLAT = 5, QUEUE_CONTINUE = 6, QUEUE_MISS = 7,
+              N_QUEUES = 8;
 
 // Division of a 32-bit number by a divisor fixed for the whole launch: a multiply-high and two shifts in
 // place of the long sequence a division compiles to (Granlund & Montgomery, unsigned case).
