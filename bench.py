@@ -4,17 +4,19 @@
 One "step" is one full render of the frame: every rank (one process per GPU) traces its
 share of the samples of every pixel into an f32 sum image resident in HBM, the sums are
 reduced to rank 0 over RCCL (only when N > 1) and rank 0 encodes the RGB24 image
-(renderer.rs:232-259).  By default every GPU traces `--spp` samples per pixel, so an N-GPU step is the
-frame at N x spp samples per pixel (scaling "weak": the work per GPU is fixed and no rank waits for another
-before the one reduce); `--scaling strong` splits the same `--spp` over the ranks instead.
+(renderer.rs:232-259).  By default the `--spp` samples of every pixel are split over the ranks (scaling
+"strong": an N-GPU step is the same frame as the one-GPU step); `--scaling weak` has every GPU trace `--spp`
+samples per pixel instead, so an N-GPU step is the frame at N x spp samples per pixel.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints one JSON line.  `roofline` prices the render kernel (one launch traces a whole
-step: camera paths, BVH walk, shading) from HIP-event durations taken inside the timed steps;
-`cpu_baseline` times the CPU oracle on a bounded sample of the same scene.
+step: camera paths, BVH walk, shading) from HIP-event durations taken inside the timed steps, against the
+roof that binds the scene: vector-ALU work when the CUs serve nodes and primitive records from their LDS copies
+of the scene, HBM bytes when those come from global memory.  `cpu_baseline` times the CPU oracle on a bounded
+sample of the same scene.
 """
 import argparse
 import json
@@ -42,38 +44,81 @@ def parse():
     ap.add_argument("--depth", type=int, default=0, help="0 = the example's own max depth")
     ap.add_argument("--pool", type=int, default=0, help="paths in flight per GPU (0 = library default)")
     ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N GPUs: weak = --spp samples per pixel on every GPU, strong = --spp split over the GPUs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N GPUs: strong = --spp split over the GPUs, weak = --spp samples per pixel on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--save", default="", help="write the last frame as PPM (rank 0)")
     return ap.parse_args()
 
 
-def measured_traffic(segments_per_launch):
-    """HBM bytes per launch from the committed counter run (FETCH_SIZE / WRITE_SIZE collected in separate
-    rocprofv3 --pmc passes over this workload, per segment), scaled to this launch; None without the file."""
-    f = ROOT / "profiles" / "hbm_traffic.json"
+def measured_traffic(scene, segments_per_launch):
+    """HBM bytes per launch from the committed counter run of this scene (FETCH_SIZE / WRITE_SIZE collected in
+    separate rocprofv3 --pmc passes, per segment), scaled to this launch; None when no such run is on file."""
+    for name in ("hbm_traffic.json", "hbm_traffic_" + scene.replace(":", "_") + ".json"):
+        f = ROOT / "profiles" / name
+        if f.exists():
+            m = json.loads(f.read_text())
+            if m.get("scene", "final_scene") == scene:
+                return m["bytes_per_segment"] * segments_per_launch
+    return None
+
+
+def valu_issue(scene, segments, kernel_seconds):
+    """Share of the chip's vector-instruction issue slots the launch used: VALU instructions per segment from the
+    committed SQ counter run of this scene x this launch's segments x the measured issue cost of a wave64
+    instruction, over SIMDs x shader clock x the launch's duration.  None when no counter run is on file."""
+    f = ROOT / "profiles" / "valu_issue.json"
     if not f.exists():
         return None
     m = json.loads(f.read_text())
-    return m["bytes_per_segment"] * segments_per_launch
+    if m.get("scene") != scene:
+        return None
+    insts = m["valu_instructions_per_segment"] * segments
+    slots = m["simds"] * m["shader_clock_ghz"] * 1e9 * kernel_seconds / m["cycles_per_wave64_instruction"]
+    return {"frac": insts / slots, "valu_instructions_per_segment": m["valu_instructions_per_segment"],
+            "cycles_per_wave64_instruction": m["cycles_per_wave64_instruction"],
+            "shader_clock_ghz": m["shader_clock_ghz"], "active_lanes": m.get("active_lanes"),
+            "source": m.get("source")}
+
+
+def host_threads():
+    """Hardware threads this process may really use: the CPUs it is allowed on, cut down to the container's CPU
+    quota where there is one (a GPU box hands a job a share of the machine; its CPU count shows the whole
+    machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    share = os.environ.get("MIRT_CPU_SHARE") or os.environ.get("OMP_NUM_THREADS")
+    if share and share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
 
 
 def cpu_baseline(scene, width, height, depth):
-    """Times the CPU oracle (the restatement of the reference's renderer) on a bounded sample."""
+    """Times the CPU oracle (the restatement of the reference's renderer: strip threads over a linear scan of the
+    World) on a bounded sample, one thread per hardware thread this job may use."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib as O
-    cores = min(16, os.cpu_count() or 1)
+    cores = host_threads()
     o = O.Scene(scene)
-    # about 12 M samples of the same framing (10-20 s of CPU work): a quarter of the resolution per axis, 96 spp
-    w, h, spp = max(2, width // 4), max(2, height // 4), 96
+    # the same framing at a quarter of the resolution per axis; spp sized to about 15 s of CPU work
+    w, h = max(2, width // 4), max(2, height // 4)
+    t0 = time.perf_counter()
+    o.render(w, h, 2, depth=depth, aspect=width / height, threads=cores)
+    probe = time.perf_counter() - t0
+    spp = int(min(1024, max(8, 15.0 / max(probe / 2, 1e-6))))
     t0 = time.perf_counter()
     _, _, segments = o.render(w, h, spp, depth=depth, aspect=width / height, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": w * h * spp / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "host_cpu_count": os.cpu_count(),
             "sample": f"{scene} {w}x{h}, {spp} spp, depth {depth}: same scene, camera and algorithm "
-                      f"(world.rs linear scan), {dt:.1f} s",
+                      f"(world.rs linear scan), {cores} threads, {dt:.1f} s",
             "segments_per_sample": segments / (w * h * spp)}
 
 
@@ -174,43 +219,59 @@ def main():
         n = ws["nodes_visited"] / max(1, ws["segments"])   # BVH nodes per segment
         p = ws["prims_tested"] / max(1, ws["segments"])    # primitive tests per segment
         roofline = None
-        valu = None
+        models = None
         if kernel_launches[R.MIRT_KERNEL_RENDER]:
-            # One launch of k_render traces a whole step.  Algorithmic bytes per segment: 192 B of path state
-            # (ray, hit, throughput, queue entry, written once and read once per stage) + a 64-B node per tree
-            # step + a 32-B primitive record per primitive test.
-            bytes_per_segment = 192 + 64 * n + 32 * p
-            my_segments = s * a.width * a.height * count * a.steps
+            launches = kernel_launches[R.MIRT_KERNEL_RENDER]
             ker_s = kernel_ms[R.MIRT_KERNEL_RENDER] / 1e3
-            achieved = my_segments * bytes_per_segment / ker_s / 1e9
+            my_segments = s * a.width * a.height * count * a.steps
+            # Per segment, two models of the work (both from the counts s, n, p measured above):
+            #   bytes  192 B of path state (ray, hit, throughput, queue entry, written once and read once per
+            #          stage) + a 64-B node per tree step + a 32-B primitive record per primitive test
+            #   flops  two slab tests per tree step (44), ~26 per primitive test, ~160 to shade a hit, three
+            #          Philox4x32-10 blocks of ~100 integer operations
+            bytes_per_segment = 192 + 64 * n + 32 * p
+            flops_per_segment = 44 * n + 26 * p + 160 + 3 * 100
+            gbs = my_segments * bytes_per_segment / ker_s / 1e9
+            tf = my_segments * flops_per_segment / ker_s / 1e12
+            traffic = measured_traffic(a.scene, my_segments / launches)
             cyc = ws["phase_cycles"]
             names = ["start_fetch", "tree_steps", "primitive_tests", "shade", "hand_in", "total"]
-            roofline = {"kernel": "k_render", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": measured_traffic(my_segments / kernel_launches[R.MIRT_KERNEL_RENDER]),
-                        "avg_launch_ms": kernel_ms[R.MIRT_KERNEL_RENDER] / kernel_launches[R.MIRT_KERNEL_RENDER],
-                        "launches": kernel_launches[R.MIRT_KERNEL_RENDER],
-                        "bytes_per_segment": bytes_per_segment,
-                        "segments_per_launch": my_segments / kernel_launches[R.MIRT_KERNEL_RENDER],
-                        "segments_per_sample": s, "nodes_per_segment": n, "prims_per_segment": p,
-                        "lanes_at_work": {"tree_steps": ws["nodes_visited"] / max(1, 64 * ws["node_wave_steps"]),
-                                          "primitive_tests": ws["prims_tested"] / max(1, 64 * ws["prim_wave_steps"])},
-                        "wave_time_share": {k: cyc[i] / max(1, cyc[5]) for i, k in enumerate(names[:5])}}
-            # two slab tests per tree step (44 flops), ~26 per primitive test, ~160 to shade a hit,
-            # three Philox4x32-10 blocks of ~100 integer operations
-            flops_per_segment = 44 * n + 26 * p + 160 + 3 * 100
-            tf = my_segments * flops_per_segment / ker_s / 1e12
-            valu = {"kernel": "k_render", "bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / VALU_PEAK_TFLOPS, "flops_per_segment": flops_per_segment}
+            common = {"kernel": "k_render", "avg_launch_ms": kernel_ms[R.MIRT_KERNEL_RENDER] / launches,
+                      "launches": launches, "segments_per_launch": my_segments / launches,
+                      "segments_per_sample": s, "nodes_per_segment": n, "prims_per_segment": p,
+                      "scene_in_lds": ws["scene_in_lds"],
+                      "lanes_at_work": {"tree_steps": ws["nodes_visited"] / max(1, 64 * ws["node_wave_steps"]),
+                                        "primitive_tests": ws["prims_tested"] / max(1, 64 * ws["prim_wave_steps"])},
+                      "wave_time_share": {k: cyc[i] / max(1, cyc[5]) for i, k in enumerate(names[:5])}}
+            if ws["scene_in_lds"]:
+                # Nodes and primitive records never leave the CU: the vector ALUs bound the launch.  HBM sees the
+                # path records only; `traffic` is what the counters measured of it.
+                roofline = {"bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": tf / VALU_PEAK_TFLOPS, "traffic": traffic,
+                            "flops_per_segment": flops_per_segment, **common}
+                roofline["issue"] = valu_issue(a.scene, my_segments / launches, ker_s / launches)
+                if traffic is not None:
+                    hbm = traffic / (ker_s / launches) / 1e9
+                    roofline["hbm_measured"] = {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": hbm / HBM_PEAK_GBS}
+            else:
+                roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                            "bytes_per_segment": bytes_per_segment, **common}
+            # both models side by side, whichever roof binds (informational)
+            models = {"bytes_per_segment": bytes_per_segment, "algorithmic_gb_per_s": gbs,
+                      "flops_per_segment": flops_per_segment, "algorithmic_tflop_per_s": tf,
+                      "note": "the byte model counts node and record reads wherever they are served from"}
+        size = "1080p" if (a.width, a.height) == (1920, 1080) else f"{a.width}x{a.height}"
         result = {
-            "metric": "Msamples/s on final_scene 1080p", "value": value, "unit": "Msamples/s", "n_gpus": world,
+            "metric": f"Msamples/s on {a.scene} {size}", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.scene} {a.width}x{a.height}, {total_spp} spp, depth {depth}",
                        "sharding": f"sample ranges over {world} GPU(s), RCCL sum-reduce of the f32 image" if world > 1
                        else "single GPU", "path_pool": ws["path_pool"], "seed": a.seed,
                        "rounds_per_step": iterations / max(1, a.steps)},
-            "roofline": roofline, "roofline_valu": valu,
+            "roofline": roofline, "work_models": models,
         }
         if not a.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(a.scene, a.width, a.height, depth)

@@ -311,6 +311,9 @@ typedef struct mirt_stats {
   uint64_t node_wave_steps; /* wave-wide turns spent stepping down the tree: nodes_visited / (64 * this) is the
                                share of lanes doing useful work in them   (MIRT_RENDER_COUNT_WORK) */
   uint64_t prim_wave_steps; /* the same for primitive tests */
+  uint32_t scene_in_lds;    /* 1: nodes and primitive records were served from the CUs' LDS copies of the scene,
+                               0: from global memory (HBM / L2) */
+  uint32_t lds_bytes;       /* LDS the render kernel's blocks were launched with */
 } mirt_stats;
 
 typedef struct mirt_ray {

@@ -142,7 +142,8 @@ class Stats(C.Structure):
                 ("path_pool", C.c_uint32), ("kernel_ms", C.c_double * MIRT_KERNEL_COUNT),
                 ("kernel_launches", C.c_uint32 * MIRT_KERNEL_COUNT),
                 ("phase_cycles", C.c_uint64 * 6),
-                ("node_wave_steps", C.c_uint64), ("prim_wave_steps", C.c_uint64)]
+                ("node_wave_steps", C.c_uint64), ("prim_wave_steps", C.c_uint64),
+                ("scene_in_lds", C.c_uint32), ("lds_bytes", C.c_uint32)]
 
     def as_dict(self):
         return {"render_ms": self.render_ms, "samples": int(self.samples), "segments": int(self.segments),
@@ -151,7 +152,8 @@ class Stats(C.Structure):
                 "kernel_ms": [float(x) for x in self.kernel_ms],
                 "kernel_launches": [int(x) for x in self.kernel_launches],
                 "phase_cycles": [int(x) for x in self.phase_cycles],
-                "node_wave_steps": int(self.node_wave_steps), "prim_wave_steps": int(self.prim_wave_steps)}
+                "node_wave_steps": int(self.node_wave_steps), "prim_wave_steps": int(self.prim_wave_steps),
+                "scene_in_lds": bool(self.scene_in_lds), "lds_bytes": int(self.lds_bytes)}
 
 
 class Ray(C.Structure):

@@ -687,6 +687,8 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   if (stats) {
     stats->render_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     stats->path_pool = pool;
+    stats->scene_in_lds = cfg.lds_scene ? 1u : 0u;
+    stats->lds_bytes = (uint32_t)cfg.lds_bytes;
     WorkCounters w{};
     MIRT_HIP(ctx, hipMemcpy(&w, ctx->work.ptr, sizeof(w), hipMemcpyDeviceToHost));
     stats->iterations = w.rounds;
