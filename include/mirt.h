@@ -347,8 +347,9 @@ int mirt_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
                 const mirt_render_params* params, uint8_t* rgb24_out, float* rgb_sum_out, mirt_stats* stats);
 
 /* Same render, adding into a caller-owned DEVICE buffer of width*height*3 f32
- * (zeroed by the caller) on `stream` (a hipStream_t, NULL = default stream).
- * Used when each rank of a multi-GPU job renders a sample range and the sums
+ * (zeroed by the caller) on `stream`, a hipStream_t; NULL is the null stream, which runs behind everything the
+ * caller queued on the null stream and on blocking streams before the call (the same holds for mirt_resolve and
+ * mirt_trace_device; work queued on a non-blocking stream has to be waited for, or that stream passed).  Used when each rank of a multi-GPU job renders a sample range and the sums
  * are then reduced across GPUs. */
 int mirt_render_accumulate(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
                            const mirt_render_params* params, float* rgb_sum_device, void* stream,

@@ -771,7 +771,7 @@ extern "C" {
 int mirt_render_accumulate(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
                            const mirt_render_params* params, float* rgb_sum_device, void* stream, mirt_stats* stats) {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
-  return render_impl(ctx, scene, camera, params, rgb_sum_device, stream ? (hipStream_t)stream : ctx->stream, stats);
+  return render_impl(ctx, scene, camera, params, rgb_sum_device, (hipStream_t)stream /* NULL: the null stream */, stats);
 }
 
 int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width, uint32_t height,
@@ -781,7 +781,7 @@ int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width,
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "bad resolve argument");
   if ((uint64_t)width * height * 3 >= (1ull << 32)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "image too large");
   MIRT_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  hipStream_t s = (hipStream_t)stream /* NULL: the null stream */;
   launch_resolve(rgb_sum_device, width * height * 3, samples_per_pixel, rgb24_device, s);
   MIRT_HIP(ctx, hipGetLastError());
   MIRT_HIP(ctx, hipStreamSynchronize(s));
@@ -831,7 +831,7 @@ int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray
   job.hit_type = type_index_device;
   job.hit_object = object_index_device;
   job.hit_t = t_device;
-  return run_job(ctx, scene, job, stream ? (hipStream_t)stream : ctx->stream, nullptr);
+  return run_job(ctx, scene, job, (hipStream_t)stream /* NULL: the null stream */, nullptr);
 }
 
 int mirt_trace_primary(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,

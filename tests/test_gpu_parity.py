@@ -196,6 +196,7 @@ def test_resolve_matches_reference_encoding(scenes):
     sums.reshape(-1)[:8] = [0.0, -0.0, np.nan, np.inf, -np.inf, -3.0, 7.0 * 0.999 ** 2, 1e-30]
     d_sum = torch.from_numpy(sums).cuda()
     d_rgb = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    # (no stream = the null stream, torch's own: the call runs behind the copy and the fill that made the buffers)
     g.resolve(d_sum.data_ptr(), w, h, spp, d_rgb.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(d_rgb.cpu().numpy(), O.encode(sums, spp))

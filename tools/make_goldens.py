@@ -11,7 +11,13 @@ the build container:
   <scene>_converged.npz     low-resolution, high-spp renders (RGB24 + mask of NaN-poisoned pixels + spp +
                             seed) used as the converged CPU image for PSNR checks
 
-Usage: python tools/make_goldens.py [primary] [spheres] [cornel_box] [final_scene]
+  <scene>_blocks.npz        the frame the benchmark times, at the benchmark's own resolution and camera, rendered
+                            by the oracle at `spp` samples per pixel and averaged over 8x8 pixel blocks: per block
+                            the mean linear radiance of its finite pixels (f32, so spp * 64 samples per value) and
+                            the number of pixels a NaN sample poisoned.  A GPU frame of the same resolution is
+                            reduced the same way and compared block by block.
+
+Usage: python tools/make_goldens.py [primary] [spheres] [cornel_box] [final_scene] [final_scene_blocks] [cornel_box_blocks]
 """
 import sys
 import time
@@ -32,7 +38,37 @@ CONVERGED = {  # name: (width, height, spp)
     "final_scene": (64, 36, 16384),
 }
 
+BLOCKS = {  # name: (scene, width, height, spp per pixel, block edge)
+    "final_scene_blocks": ("final_scene", 1920, 1080, 256, 8),
+    "cornel_box_blocks": ("cornel_box", 1000, 1000, 256, 8),
+}
+
+
+def block_means(sums, spp, block):
+    """Mean linear radiance over the finite pixels of each block x block tile, and the poisoned-pixel count."""
+    h, w, _ = sums.shape
+    finite = np.isfinite(sums).all(axis=2)
+    lin = np.where(finite[..., None], sums.astype(np.float64) / spp, 0.0)
+    hb, wb = h // block, w // block
+    lin = lin[:hb * block, :wb * block].reshape(hb, block, wb, block, 3).sum(axis=(1, 3))
+    cnt = finite[:hb * block, :wb * block].reshape(hb, block, wb, block).sum(axis=(1, 3))
+    mean = lin / np.maximum(cnt, 1)[..., None]
+    return mean.astype(np.float32), (block * block - cnt).astype(np.uint8)
+
+
 what = sys.argv[1:] or ["primary"] + list(CONVERGED)
+for name, (scene, w, h, spp, block) in BLOCKS.items():
+    if name not in what:
+        continue
+    t0 = time.time()
+    s = O.Scene(scene, scene_seed=1)
+    threads = max(1, (len(__import__("os").sched_getaffinity(0))) - 1)
+    _, sums, seg = s.render(w, h, spp, aspect=w / h, seed=SEED, threads=threads)
+    mean, poisoned = block_means(sums, spp, block)
+    np.savez_compressed(GOLD / f"{name}.npz", mean=mean, poisoned=poisoned, width=w, height=h, spp=spp, block=block,
+                        seed=SEED, scene_seed=1, depth=s.depth, aspect=np.float32(w / h),
+                        segments_per_sample=np.float64(seg / (w * h * spp)))
+    print(name, w, h, spp, round(time.time() - t0, 1), "s", flush=True)
 if "primary" in what:
     s = O.Scene("spheres_bvh", scene_seed=1)
     cam, _ = s.camera()
