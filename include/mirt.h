@@ -355,6 +355,19 @@ int mirt_render_accumulate(mirt_context* ctx, const mirt_scene* scene, const mir
                            const mirt_render_params* params, float* rgb_sum_device, void* stream,
                            mirt_stats* stats);
 
+/* mirt_render_accumulate for callers that may not allocate device memory (code under HIP graph capture, serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The path pool, the counters
+ * and the launch arguments live in a fixed workspace the library holds on every GPU (about 40 MiB); the call
+ * makes no hipMalloc / hipFree and creates no events, so MIRT_RENDER_TIME_KERNELS is rejected.  The workspace holds
+ * mirt_static_workspace_paths() paths in flight: params->path_pool = 0 uses all of them, a larger path_pool is
+ * rejected with MIRT_ERR_INVALID_ARGUMENT (images of any size are rendered through the pool; the small pool makes
+ * this entry point slower than mirt_render_accumulate).  All calls on one GPU share its workspace: two such
+ * calls that overlap on one GPU race, whatever their contexts and streams. */
+int mirt_render_accumulate_static(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
+                                  const mirt_render_params* params, float* rgb_sum_device, void* stream,
+                                  mirt_stats* stats);
+int mirt_static_workspace_paths(void);
+
 /* renderer.rs:232-259 on the device: sums of `samples_per_pixel` samples ->
  * RGB24.  Both pointers are device pointers. */
 int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width, uint32_t height,

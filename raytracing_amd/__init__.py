@@ -161,7 +161,8 @@ class Ray(C.Structure):
 
 
 MIRT_SYMBOLS = ["mirt_context_create", "mirt_context_destroy", "mirt_last_error", "mirt_scene_upload",
-                "mirt_scene_destroy", "mirt_render", "mirt_render_accumulate", "mirt_resolve",
+                "mirt_scene_destroy", "mirt_render", "mirt_render_accumulate", "mirt_render_accumulate_static",
+                "mirt_static_workspace_paths", "mirt_resolve",
                 "mirt_trace_primary", "mirt_trace_device", "mirt_version"]
 
 
@@ -197,6 +198,9 @@ def mirt():
     L.mirt_render.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     L.mirt_render_accumulate.restype = C.c_int
     L.mirt_render_accumulate.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    L.mirt_render_accumulate_static.restype = C.c_int
+    L.mirt_render_accumulate_static.argtypes = L.mirt_render_accumulate.argtypes
+    L.mirt_static_workspace_paths.restype = C.c_int
     L.mirt_resolve.restype = C.c_int
     L.mirt_resolve.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.mirt_trace_primary.restype = C.c_int

@@ -16,6 +16,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "scene_device.h"
@@ -1661,6 +1662,34 @@ __global__ void k_resolve(const float* __restrict__ rgb_sum, uint32_t n_values, 
 }
 
 }  // namespace
+
+// ---- the fixed workspace ------------------------------------------------------------------
+// Every GPU the library is loaded on holds its own copy of this array, at its own address, until the process
+// ends.  In host code the array's name only stands for the symbol: the address a kernel can use comes from
+// hipGetSymbolAddress, asked once per device with that device current, and is what the host passes around.
+static __device__ __align__(256) unsigned char scratch[STATIC_WORKSPACE_BYTES];
+
+hipError_t static_workspace_address(int device, void** out) {
+  constexpr int MAX_DEVICES = 64;
+  static std::mutex guard;
+  static void* address[MAX_DEVICES] = {};
+  *out = nullptr;
+  if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(guard);
+  if (!address[device]) {
+    int current = -1;
+    hipError_t e = hipGetDevice(&current);
+    if (e != hipSuccess) return e;
+    if (current != device) return hipErrorInvalidDevice;
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    address[device] = p;
+  }
+  *out = address[device];
+  return hipSuccess;
+}
 
 // ---- launchers ------------------------------------------------------------------------
 RenderConfig plan_render(const DeviceScene& sc) {

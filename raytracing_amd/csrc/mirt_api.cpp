@@ -65,6 +65,7 @@ struct mirt_context {
   DeviceBuffer work;
   DeviceBuffer image_sum;
   DeviceBuffer image_rgb;
+  void* static_workspace = nullptr;  // this device's copy of the library's fixed workspace (kernels.hip)
 };
 
 struct mirt_scene {
@@ -262,6 +263,13 @@ int mirt_context_create(int device_id, mirt_context** out) {
   if (e != hipSuccess) {
     delete ctx;
     return fail(nullptr, MIRT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  // (device_id is current: every GPU holds its own copy of the fixed workspace at its own address)
+  e = static_workspace_address(device_id, &ctx->static_workspace);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return fail(nullptr, MIRT_ERR_DEVICE, std::string("hipGetSymbolAddress(static workspace): ") + hipGetErrorString(e));
   }
   *out = ctx;
   return MIRT_OK;
@@ -608,30 +616,69 @@ struct Job {
   float* hit_t = nullptr;
   uint64_t want_pool = 0;
   uint32_t flags = 0;
+  bool fixed_workspace = false;  // work in the library's fixed workspace: no allocation of any kind
 };
+
+// Device memory a job works in besides its inputs and outputs.
+struct Workspace {
+  float4* paths[2];
+  float4* queues;
+  RenderState* state;
+  WorkCounters* work;
+  RenderArgs* args;
+};
+
+// The fixed workspace, cut up: [control page: state, counters, arguments][paths a][paths b][queues].
+Workspace carve_static_workspace(void* base) {
+  static_assert(sizeof(RenderState) <= 256 && sizeof(WorkCounters) <= 256 && sizeof(RenderArgs) <= STATIC_CONTROL_BYTES - 512,
+                "the control page of the fixed workspace is too small");
+  unsigned char* p = static_cast<unsigned char*>(base);
+  Workspace w;
+  w.state = reinterpret_cast<RenderState*>(p);
+  w.work = reinterpret_cast<WorkCounters*>(p + 256);
+  w.args = reinterpret_cast<RenderArgs*>(p + 512);
+  p += STATIC_CONTROL_BYTES;
+  w.paths[0] = reinterpret_cast<float4*>(p);
+  w.paths[1] = reinterpret_cast<float4*>(p + (size_t)STATIC_POOL_PATHS * 64);
+  w.queues = reinterpret_cast<float4*>(p + (size_t)STATIC_POOL_PATHS * 128);
+  return w;
+}
 
 // Sizes the path pool, launches the render kernel once and waits for it.
 int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t stream, mirt_stats* stats) {
   const uint64_t total = job.rc.total_paths;
+  if (job.fixed_workspace && job.want_pool > STATIC_POOL_PATHS)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "path_pool beyond the " + std::to_string(STATIC_POOL_PATHS) +
+                                                    " paths the fixed workspace holds");
   // paths in flight: a whole number of waves per region, no more than the job has paths
-  uint64_t want = job.want_pool ? job.want_pool : (1u << 23);
+  uint64_t want = job.want_pool ? job.want_pool : (job.fixed_workspace ? STATIC_POOL_PATHS : (1u << 23));
   want = std::min<uint64_t>(want, total);
   want = std::min<uint64_t>(std::max<uint64_t>(want, POOL_GRANULE), 1u << 27);
   const uint32_t pool = (uint32_t)((want + POOL_GRANULE - 1) / POOL_GRANULE * POOL_GRANULE);
   job.rc.pool = pool;
   job.rc.region_cap = pool / N_REGIONS;
 
-  MIRT_HIP(ctx, ctx->paths[0].ensure((size_t)pool * 64));
-  MIRT_HIP(ctx, ctx->paths[1].ensure((size_t)pool * 64));
-  MIRT_HIP(ctx, ctx->queues.ensure((size_t)pool * 64 * N_QUEUES));
-  MIRT_HIP(ctx, ctx->state.ensure(sizeof(RenderState)));
-  MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
-  MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
-  MIRT_HIP(ctx, hipMemsetAsync(ctx->state.ptr, 0, sizeof(RenderState), stream));
-  MIRT_HIP(ctx, hipMemsetAsync(ctx->work.ptr, 0, sizeof(WorkCounters), stream));
+  Workspace ws;
+  if (job.fixed_workspace) {
+    if (pool > STATIC_POOL_PATHS) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "pool beyond the fixed workspace");
+    if (!ctx->static_workspace) return fail(ctx, MIRT_ERR_DEVICE, "the fixed workspace of this device was not found");
+    ws = carve_static_workspace(ctx->static_workspace);
+  } else {
+    MIRT_HIP(ctx, ctx->paths[0].ensure((size_t)pool * 64));
+    MIRT_HIP(ctx, ctx->paths[1].ensure((size_t)pool * 64));
+    MIRT_HIP(ctx, ctx->queues.ensure((size_t)pool * 64 * N_QUEUES));
+    MIRT_HIP(ctx, ctx->state.ensure(sizeof(RenderState)));
+    MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
+    MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
+    ws = Workspace{{ctx->paths[0].as<float4>(), ctx->paths[1].as<float4>()}, ctx->queues.as<float4>(),
+                   ctx->state.as<RenderState>(), ctx->work.as<WorkCounters>(), ctx->args.as<RenderArgs>()};
+  }
+  // (the workspace keeps the last call's contents: the counters must start at zero, the rest is written before read)
+  MIRT_HIP(ctx, hipMemsetAsync(ws.state, 0, sizeof(RenderState), stream));
+  MIRT_HIP(ctx, hipMemsetAsync(ws.work, 0, sizeof(WorkCounters), stream));
 
   const bool count_work = (job.flags & MIRT_RENDER_COUNT_WORK) != 0;
-  const bool time_kernels = (job.flags & MIRT_RENDER_TIME_KERNELS) != 0;
+  const bool time_kernels = (job.flags & MIRT_RENDER_TIME_KERNELS) != 0 && !job.fixed_workspace;
   const RenderConfig cfg = plan_render(scene->view);
   if (std::getenv("MIRT_VERBOSE"))
     std::fprintf(stderr, "mirt: %zu prims, %u nodes, height %u; %s, %d x %d threads, %zu B LDS, stack %d; pool %u\n",
@@ -653,11 +700,11 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   RenderArgs args{};
   args.sc = scene->view;
   args.rc = job.rc;
-  args.paths_a = ctx->paths[0].as<float4>();
-  args.paths_b = ctx->paths[1].as<float4>();
-  args.queues = ctx->queues.as<float4>();
-  args.state = ctx->state.as<RenderState>();
-  args.work = ctx->work.as<WorkCounters>();
+  args.paths_a = ws.paths[0];
+  args.paths_b = ws.paths[1];
+  args.queues = ws.queues;
+  args.state = ws.state;
+  args.work = ws.work;
   args.rgb_sum = job.rgb_sum;
   args.refill_min = cfg.refill_min;
   args.chunk_len = 0.0f;
@@ -679,8 +726,8 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.hit_object = job.hit_object;
   args.hit_t = job.hit_t;
   // (pageable source: the copy has left `args` by the time the call returns)
-  MIRT_HIP(ctx, hipMemcpyAsync(ctx->args.ptr, &args, sizeof(args), hipMemcpyHostToDevice, stream));
-  MIRT_HIP(ctx, launch_render(ctx->args.as<RenderArgs>(), count_work, cfg, stream));
+  MIRT_HIP(ctx, hipMemcpyAsync(ws.args, &args, sizeof(args), hipMemcpyHostToDevice, stream));
+  MIRT_HIP(ctx, launch_render(ws.args, count_work, cfg, stream));
   if (time_kernels) MIRT_HIP(ctx, hipEventRecord(ev[1], stream));
   MIRT_HIP(ctx, hipStreamSynchronize(stream));
   const auto t_end = std::chrono::steady_clock::now();
@@ -690,7 +737,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
     stats->scene_in_lds = cfg.lds_scene ? 1u : 0u;
     stats->lds_bytes = (uint32_t)cfg.lds_bytes;
     WorkCounters w{};
-    MIRT_HIP(ctx, hipMemcpy(&w, ctx->work.ptr, sizeof(w), hipMemcpyDeviceToHost));
+    MIRT_HIP(ctx, hipMemcpy(&w, ws.work, sizeof(w), hipMemcpyDeviceToHost));
     stats->iterations = w.rounds;
     if (count_work) {
       stats->segments = w.segments;
@@ -711,7 +758,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
 }
 
 int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera, const mirt_render_params* params,
-                float* rgb_sum_device, hipStream_t stream, mirt_stats* stats) {
+                float* rgb_sum_device, hipStream_t stream, mirt_stats* stats, bool fixed_workspace = false) {
   if (!scene || !camera || !params || !rgb_sum_device) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   const mirt_render_params& p = *params;
   if (p.width < 2 || p.height < 2) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
@@ -761,6 +808,7 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   job.rgb_sum = rgb_sum_device;
   job.want_pool = p.path_pool;
   job.flags = p.flags;
+  job.fixed_workspace = fixed_workspace;
   return run_job(ctx, scene, job, stream, stats);
 }
 
@@ -773,6 +821,17 @@ int mirt_render_accumulate(mirt_context* ctx, const mirt_scene* scene, const mir
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   return render_impl(ctx, scene, camera, params, rgb_sum_device, (hipStream_t)stream /* NULL: the null stream */, stats);
 }
+
+int mirt_render_accumulate_static(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
+                                  const mirt_render_params* params, float* rgb_sum_device, void* stream,
+                                  mirt_stats* stats) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (params && (params->flags & MIRT_RENDER_TIME_KERNELS))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "MIRT_RENDER_TIME_KERNELS creates events: not available without allocation");
+  return render_impl(ctx, scene, camera, params, rgb_sum_device, (hipStream_t)stream /* NULL: the null stream */, stats, true);
+}
+
+int mirt_static_workspace_paths(void) { return (int)STATIC_POOL_PATHS; }
 
 int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width, uint32_t height,
                  uint32_t samples_per_pixel, uint8_t* rgb24_device, void* stream) {

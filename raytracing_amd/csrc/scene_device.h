@@ -211,6 +211,16 @@ struct RenderConst {
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
 constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
+// ---- the fixed workspace ----------------------------------------------------------
+// For callers that may not allocate device memory: a file-scope device array in kernels.hip, one copy per GPU,
+// holding a path pool of STATIC_POOL_PATHS records (two record buffers and N_QUEUES queues: 640 bytes a path)
+// behind a control page with the render's counters and launch arguments.
+constexpr uint32_t STATIC_POOL_PATHS = 65536;
+constexpr size_t STATIC_CONTROL_BYTES = 4096;
+constexpr size_t STATIC_WORKSPACE_BYTES = STATIC_CONTROL_BYTES + (size_t)STATIC_POOL_PATHS * 64 * (2 + N_QUEUES);
+// Address of the current device's copy (`device` must be the current device); looked up once per device.
+hipError_t static_workspace_address(int device, void** out);
+
 // ---- launchers implemented in kernels.hip ------------------------------------
 // How the render kernel is launched for a scene: one 1024-thread block per region, with nodes, primitive
 // records, wrapper chains, materials, textures and the light list staged in LDS when they fit beside the block's

@@ -1,0 +1,61 @@
+"""mirt_render_accumulate_static (the entry point that allocates nothing) against mirt_render_accumulate, through
+the C ABI: same scene, camera, seed and samples.  With two samples per pixel every channel of the image is the sum
+of at most two terms added to zero, so the order of the device's atomic adds cannot change a bit and the images
+must be identical; at 16 samples per pixel the order may differ and the tolerance is a few f32 roundings."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import raytracing_amd as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(entry, g, width, height, spp, pool=0, flags=0):
+    L = R.mirt()
+    cam, bg = g.camera(width / height)
+    p = R.RenderParams(width, height, spp, 0, g.depth, (C.c_float * 3)(*bg), 11, pool, flags)
+    sums = torch.zeros((height, width, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    st = R.Stats()
+    ctx, scene = g.L.rt_example_context(g.h), g.L.rt_example_scene(g.h)
+    rc = entry(ctx, scene, C.byref(cam), C.byref(p), C.c_void_p(sums.data_ptr()), None, C.byref(st))
+    msg = L.mirt_last_error(ctx).decode() if rc else ""
+    return rc, msg, sums.cpu().numpy(), st.as_dict()
+
+
+@pytest.mark.parametrize("scene", ["final_scene", "synthetic_bvh:40"])   # scene served from LDS / from global memory
+def test_static_workspace_render_equals_allocating_render(scene):
+    L = R.mirt()
+    g = R.ExampleScene(scene)
+    # two calls in a row on the shared workspace, the second one smaller
+    for width, height in ((320, 180), (96, 54)):
+        rc, msg, ref, st_ref = _render(L.mirt_render_accumulate, g, width, height, 2)
+        assert rc == 0, msg
+        rc, msg, got, st = _render(L.mirt_render_accumulate_static, g, width, height, 2)
+        assert rc == 0, msg
+        assert st["path_pool"] <= L.mirt_static_workspace_paths()
+        assert st["samples"] == st_ref["samples"] == width * height * 2
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "2-spp images differ bitwise"
+        assert np.isfinite(ref).all() and ref.max() > 0
+    rc, msg, ref, _ = _render(L.mirt_render_accumulate, g, 96, 54, 16)
+    assert rc == 0, msg
+    rc, msg, got, _ = _render(L.mirt_render_accumulate_static, g, 96, 54, 16)
+    assert rc == 0, msg
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-6)   # 16 adds per pixel in another order
+    g.close()
+
+
+def test_static_workspace_rejects_what_it_cannot_hold():
+    L = R.mirt()
+    g = R.ExampleScene("cornel_box")
+    limit = L.mirt_static_workspace_paths()
+    rc, msg, _, _ = _render(L.mirt_render_accumulate_static, g, 64, 64, 1, pool=limit + 1)
+    assert rc == 1 and "fixed workspace" in msg                     # MIRT_ERR_INVALID_ARGUMENT
+    rc, msg, _, _ = _render(L.mirt_render_accumulate_static, g, 64, 64, 1, flags=R.MIRT_RENDER_TIME_KERNELS)
+    assert rc == 1 and "allocation" in msg
+    rc, msg, img, st = _render(L.mirt_render_accumulate_static, g, 64, 64, 1, pool=limit)
+    assert rc == 0 and st["path_pool"] <= limit, msg
+    g.close()
