@@ -322,6 +322,21 @@ typedef struct mirt_ray {
   float time;
 } mirt_ray;
 
+/* What Hittable::hit hands to the integrator for one ray (HitRecord, hittable.rs:8-16, after every wrapper the
+ * object sits in) plus what its material makes of it before any random draw. */
+typedef struct mirt_hit_record {
+  float point[3];
+  float t;               /* +inf for a miss; every other field of a miss is zero, the indices 0xFFFFFFFF */
+  float normal[3];       /* as stored in the record: facing the ray, except where a wrapper left it (transforms.rs) */
+  uint32_t front_face;
+  float u, v;
+  uint32_t type_index;   /* WorldIndex of the top-level object (world.rs:13-17) */
+  uint32_t object_index;
+  float color[3];        /* Lambertian / Metal: albedo.color(u, v, point) (material.rs:40-49, 66-90); Dielectric: 1,1,1;
+                            DiffuseLight: what it emits towards the ray (material.rs:151-158); Isotropic: 0 */
+  uint32_t material_kind; /* MIRT_MAT_* */
+} mirt_hit_record;
+
 /* ---- entry points ----------------------------------------------------------- */
 
 /* Creates a context on one GPU (`device_id`, a HIP device ordinal).  There is
@@ -379,6 +394,11 @@ int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width,
  * draw from the Philox stream of (pixel = ray index, sample 0, bounce 0). */
 int mirt_trace_primary(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,
                        uint32_t* type_index, uint32_t* object_index, float* t);
+
+/* mirt_trace_primary with the whole record of every hit: what shading works with.  `records` is a host array
+ * of n. */
+int mirt_trace_records(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,
+                       mirt_hit_record* records);
 
 /* Device-resident variant used for timing the traversal alone: rays is a
  * device array of n mirt_ray, outputs are device arrays of n. */

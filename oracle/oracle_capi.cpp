@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstring>
 #include <thread>
 
 using namespace oracle;
@@ -429,6 +430,52 @@ int oracle_scene_hit_records(void* h, const float* rays, size_t n, uint64_t seed
   return 0;
 }
 
+// The same with the object's WorldIndex and what the record's material makes of the hit before any random draw
+// matters: 16 words per ray in the layout of the device library's mirt_hit_record --
+// point(3), t, normal(3), front_face (u32), u, v, type_index (u32), object_index (u32), colour(3), hit flag (u32).
+// colour = ScatterRecord::attenuation when the material scatters (material.rs:40-49, 66-90, 111-137), else what it
+// emits towards the ray (material.rs:151-158; renderer.rs:151-154 evaluates emit before scatter).
+int oracle_scene_hit_records_full(void* h, const float* rays, size_t n, uint64_t seed, float* out) {
+  Scene* s = static_cast<Scene*>(h);
+  if (!s || !s->error.empty()) return 1;
+  Sampler sampler;
+  sampler.key[0] = (uint32_t)seed;
+  sampler.key[1] = (uint32_t)(seed >> 32);
+  tls_sampler() = &sampler;
+  auto put_u32 = [](float* dst, uint32_t v) { std::memcpy(dst, &v, 4); };
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = rays + 7 * i;
+    const Ray r(Point3(p[0], p[1], p[2]), Vec3(p[3], p[4], p[5]), p[6]);
+    sampler.pixel = (uint32_t)i;
+    sampler.sample = 0;
+    sampler.begin(0, STAGE_MEDIA);
+    HitRecord rec;
+    WorldIndex who;
+    const bool ok = s->bvh ? s->bvh->hit_indexed(r, 0.001f, INF_F, rec, who) : s->world->hit_indexed(r, 0.001f, INF_F, rec, who);
+    float* o = out + 16 * i;
+    for (int k = 0; k < 16; ++k) o[k] = 0.0f;
+    o[3] = INF_F;
+    put_u32(o + 10, 0xFFFFFFFFu);
+    put_u32(o + 11, 0xFFFFFFFFu);
+    if (!ok) continue;
+    o[0] = rec.point.x; o[1] = rec.point.y; o[2] = rec.point.z; o[3] = rec.t;
+    o[4] = rec.normal.x; o[5] = rec.normal.y; o[6] = rec.normal.z;
+    put_u32(o + 7, rec.front_face ? 1u : 0u);
+    o[8] = rec.u; o[9] = rec.v;
+    put_u32(o + 10, who.type_index);
+    put_u32(o + 11, who.object_index);
+    sampler.begin(0, STAGE_SHADE);
+    ScatterRecord sr;
+    Color c;
+    if (rec.material->scatter(r, rec, sr)) c = sr.attenuation;
+    else c = rec.material->emit(r, rec, rec.u, rec.v, rec.point);
+    o[12] = c.x; o[13] = c.y; o[14] = c.z;
+    put_u32(o + 15, 1u);
+  }
+  tls_sampler() = nullptr;
+  return 0;
+}
+
 // ---- small known-answer helpers -------------------------------------------
 void oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { Philox::block(ctr, key, out); }
 
@@ -484,6 +531,104 @@ void oracle_kat_dielectric(float ior, const float dir[3], const float normal[3],
 }
 
 uint8_t oracle_kat_encode(float sum, uint32_t spp) { return encode_channel(sum, spp); }
+
+static void put_hit(const HitRecord& h, float out[10]) {
+  out[0] = h.t; out[1] = h.u; out[2] = h.v; out[3] = h.front_face ? 1.0f : 0.0f;
+  out[4] = h.point.x; out[5] = h.point.y; out[6] = h.point.z;
+  out[7] = h.normal.x; out[8] = h.normal.y; out[9] = h.normal.z;
+}
+
+// A unit of transforms.rs around a sphere (p = cx,cy,cz,r):
+// wrapper 1 Translate(offset = wp[0..3]); 2 Rotate(angle = wp[3] degrees); 3 FlipFace;
+//         4 Translate(Rotate(sphere, wp[3]), wp[0..3]) as cornel_box.rs:90-99 nests them.
+// out as oracle_kat_hit.
+int oracle_kat_wrapped_sphere(int wrapper, const float wp[4], const float p[4], const float ray[7], float t_min,
+                              float t_max, float out[10]) {
+  const LambSolid m(SolidTexture(Color(0.5f, 0.5f, 0.5f)));
+  using S = Sphere<LambSolid>;
+  const S sphere(Point3(p[0], p[1], p[2]), p[3], m);
+  const Vec3 offset(wp[0], wp[1], wp[2]);
+  const Ray r(Point3(ray[0], ray[1], ray[2]), Vec3(ray[3], ray[4], ray[5]), ray[6]);
+  HitRecord h;
+  bool ok = false;
+  switch (wrapper) {
+    case 1: ok = Translate<S>(sphere, offset).hit(r, t_min, t_max, h); break;
+    case 2: ok = Rotate<S>(sphere, wp[3]).hit(r, t_min, t_max, h); break;
+    case 3: ok = FlipFace<S>(sphere).hit(r, t_min, t_max, h); break;
+    case 4: ok = Translate<Rotate<S>>(Rotate<S>(sphere, wp[3]), offset).hit(r, t_min, t_max, h); break;
+    default: return -1;
+  }
+  if (ok) put_hit(h, out);
+  return ok ? 1 : 0;
+}
+
+// ConstantMedium (transforms.rs:117-185) over a sphere boundary; the free-flight draw is draw 0 of the media
+// stream of (pixel, sample 0, bounce 0) under `seed`, which oracle_philox lets a test work out for itself.
+int oracle_kat_medium(const float sphere[4], float density, const float ray[7], float t_min, float t_max,
+                      uint64_t seed, uint32_t pixel, float out[10]) {
+  const LambSolid m(SolidTexture(Color(0.5f, 0.5f, 0.5f)));
+  ConstantMedium<Sphere<Dielectric>, LambSolid> medium(
+      Sphere<Dielectric>(Point3(sphere[0], sphere[1], sphere[2]), sphere[3], Dielectric(1.5f)), density, m);
+  Sampler sampler;
+  sampler.key[0] = (uint32_t)seed;
+  sampler.key[1] = (uint32_t)(seed >> 32);
+  sampler.pixel = pixel;
+  sampler.begin(0, STAGE_MEDIA);
+  tls_sampler() = &sampler;
+  HitRecord h;
+  const bool ok = medium.hit(Ray(Point3(ray[0], ray[1], ray[2]), Vec3(ray[3], ray[4], ray[5]), ray[6]), t_min, t_max, h);
+  tls_sampler() = nullptr;
+  if (ok) put_hit(h, out);
+  return ok ? 1 : 0;
+}
+
+// Hittable::pdf_value: kind 0 sphere p = cx,cy,cz,r (objects.rs:82-94); 2 XZ rect p = x0,x1,z0,z1,k (objects.rs:292-301);
+// 1 XY rect, which keeps the trait's default (hittable.rs:52-54).
+float oracle_kat_pdf_value(int kind, const float* p, const float origin[3], const float dir[3]) {
+  const LambSolid m(SolidTexture(Color(0.5f, 0.5f, 0.5f)));
+  const Point3 o(origin[0], origin[1], origin[2]);
+  const Vec3 d(dir[0], dir[1], dir[2]);
+  if (kind == 0) return Sphere<LambSolid>(Point3(p[0], p[1], p[2]), p[3], m).pdf_value(o, d);
+  if (kind == 1) return XYRect<LambSolid>(p[0], p[1], p[2], p[3], p[4], m).pdf_value(o, d);
+  return XZRect<LambSolid>(p[0], p[1], p[2], p[3], p[4], m).pdf_value(o, d);
+}
+
+// MixturePdf(HittablePdf(XZ rect light, origin), CosinePdf(normal)).value(dir)   pdf.rs:25-32,60-62,81-83
+float oracle_kat_mixture_value(const float rect[5], const float origin[3], const float normal[3], const float dir[3]) {
+  const LambSolid m(SolidTexture(Color(0.5f, 0.5f, 0.5f)));
+  const XZRect<LambSolid> light(rect[0], rect[1], rect[2], rect[3], rect[4], m);
+  const HittablePdf light_pdf(&light, Point3(origin[0], origin[1], origin[2]));
+  const CosinePdf cosine_pdf(Vec3(normal[0], normal[1], normal[2]));
+  return MixturePdf(&light_pdf, &cosine_pdf).value(Vec3(dir[0], dir[1], dir[2]));
+}
+
+// Perlin::noise (depth 0) or Perlin::turb(p, depth) with tables the caller supplies (perlin.rs:26-60, 75-93).
+float oracle_kat_perlin(const float vec[256 * 3], const uint32_t perm_x[256], const uint32_t perm_y[256],
+                        const uint32_t perm_z[256], const float p[3], uint32_t depth) {
+  SceneRng rng(1);
+  Perlin pn(rng);
+  for (int i = 0; i < 256; ++i) {
+    pn.random_vec[i] = Vec3(vec[3 * i], vec[3 * i + 1], vec[3 * i + 2]);
+    pn.perm_x[i] = perm_x[i]; pn.perm_y[i] = perm_y[i]; pn.perm_z[i] = perm_z[i];
+  }
+  const Point3 q(p[0], p[1], p[2]);
+  return depth == 0 ? pn.noise(q) : pn.turb(q, depth);
+}
+
+// ImageTexture::color(u, v) over a caller-supplied RGB8 image (texture.rs:101-122).
+void oracle_kat_image_texel(const uint8_t* rgb8, uint32_t width, uint32_t height, float u, float v, float out[3]) {
+  auto data = std::make_shared<std::vector<uint8_t>>(rgb8, rgb8 + (size_t)width * height * 3);
+  const Color c = ImageTexture(data, width, height).color(u, v, Point3());
+  out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+
+void oracle_kat_sphere_uv(const float p[3], float out[2]) { get_sphere_uv(Point3(p[0], p[1], p[2]), out[0], out[1]); }
+
+// CheckerTexture over two solid colours (texture.rs:51-60): returns 1 when the odd texture answers.
+int oracle_kat_checker_is_odd(const float p[3]) {
+  const auto t = checker_from_colors(Color(1.0f, 0.0f, 0.0f), Color(0.0f, 0.0f, 0.0f));
+  return t.color(0.0f, 0.0f, Point3(p[0], p[1], p[2])).x == 1.0f ? 1 : 0;
+}
 
 // AABB::hit as written in aabb.rs (always true for t_max > t_min on this path).
 int oracle_kat_aabb_hit(const float box[6], const float ray[7], float t_min, float t_max) {

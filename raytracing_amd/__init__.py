@@ -163,7 +163,7 @@ class Ray(C.Structure):
 MIRT_SYMBOLS = ["mirt_context_create", "mirt_context_destroy", "mirt_last_error", "mirt_scene_upload",
                 "mirt_scene_destroy", "mirt_render", "mirt_render_accumulate", "mirt_render_accumulate_static",
                 "mirt_static_workspace_paths", "mirt_resolve",
-                "mirt_trace_primary", "mirt_trace_device", "mirt_version"]
+                "mirt_trace_primary", "mirt_trace_records", "mirt_trace_device", "mirt_version"]
 
 
 def build(verbose=False):
@@ -205,6 +205,8 @@ def mirt():
     L.mirt_resolve.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.mirt_trace_primary.restype = C.c_int
     L.mirt_trace_primary.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, vp, vp, vp]
+    L.mirt_trace_records.restype = C.c_int
+    L.mirt_trace_records.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, vp]
     L.mirt_trace_device.restype = C.c_int
     L.mirt_trace_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp]
     L.mirt_version.restype = C.c_int
@@ -327,6 +329,23 @@ class ExampleScene:
         t = np.zeros(n, np.float32)
         self._check(self.L.rt_example_trace(self.h, _ptr(rays), n, seed, _ptr(ti), _ptr(oi), _ptr(t)))
         return ti, oi, t
+
+
+RECORD_DTYPE = np.dtype([("point", np.float32, 3), ("t", np.float32), ("normal", np.float32, 3),
+                         ("front_face", np.uint32), ("u", np.float32), ("v", np.float32), ("type_index", np.uint32),
+                         ("object_index", np.uint32), ("color", np.float32, 3), ("material_kind", np.uint32)])
+
+
+def trace_records(example, rays, seed=7):
+    """mirt_trace_records on an ExampleScene: rays n x 7 f32 -> structured array in the layout of mirt_hit_record."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 7)
+    out = np.zeros(rays.shape[0], RECORD_DTYPE)
+    L = mirt()
+    ctx, scene = example.L.rt_example_context(example.h), example.L.rt_example_scene(example.h)
+    rc = L.mirt_trace_records(ctx, scene, _ptr(rays), rays.shape[0], seed, _ptr(out))
+    if rc != 0:
+        raise MirtError(f"status {rc}: {L.mirt_last_error(ctx).decode()}")
+    return out
 
 
 def shard_samples(spp, world_size, rank):

@@ -1484,6 +1484,13 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
   uint32_t* const hit_type = A->hit_type;
   uint32_t* const hit_object = A->hit_object;
   float* const hit_t = A->hit_t;
+  float4* const hit_records = A->hit_records;  // optional: the whole hit record of every ray
+  constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
+  ShadeTables sc = MIRT_SHADE_TABLES(A->sc);
+  if (LDS_SCENE) {
+    sc.materials = reinterpret_cast<const DMaterial*>(lds.materials);
+    sc.textures = reinterpret_cast<const DTexture*>(lds.textures);
+  }
   for (uint32_t q = 0; q < N_QUEUES; ++q) {
     const uint32_t n_q = sh.queue_n[q];
     const float4* entries = region_queues + 4 * (size_t)q * cap;
@@ -1513,6 +1520,31 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
       hit_type[g] = ti;
       hit_object[g] = oi;
       hit_t[g] = ref != REF_NONE ? t : kInf;
+      if (hit_records) {
+        // the record shading would work with (hittable.rs:8-42 after every wrapper), and what the material makes
+        // of it before any random draw: the albedo a Lambertian or Metal scatters with (material.rs:40-49,66-90),
+        // white for a Dielectric (:111-137), what a DiffuseLight emits (:151-158), nothing for an Isotropic
+        float4 o0 = make_float4(0.0f, 0.0f, 0.0f, kInf), o1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o2 = o1, o3 = o1;
+        o2.z = __uint_as_float(ti); o2.w = __uint_as_float(oi);
+        if (ref != REF_NONE) {
+          Hit h = hit_record<PSTRIDE>(tb, sh.media, ref, r, t, __float_as_uint(r3.z));
+          if (h.sphere_uv) sphere_uv(h.on_sphere, h.u, h.v);
+          const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
+          V3 color = v3(0.0f, 0.0f, 0.0f);
+          if (m.kind == MIRT_MAT_LAMBERTIAN || m.kind == MIRT_MAT_METAL || (m.kind == MIRT_MAT_DIFFUSE_LIGHT && h.front))
+            color = texture_color(sc, m.texture, h);
+          else if (m.kind == MIRT_MAT_DIELECTRIC)
+            color = v3(1.0f, 1.0f, 1.0f);
+          o0 = make_float4(h.p.x, h.p.y, h.p.z, h.t);
+          o1 = make_float4(h.n.x, h.n.y, h.n.z, __uint_as_float(h.front ? 1u : 0u));
+          o2.x = h.u; o2.y = h.v;
+          o3 = make_float4(color.x, color.y, color.z, __uint_as_float(m.kind));
+        }
+        hit_records[4 * (size_t)g] = o0;
+        hit_records[4 * (size_t)g + 1] = o1;
+        hit_records[4 * (size_t)g + 2] = o2;
+        hit_records[4 * (size_t)g + 3] = o3;
+      }
     }
   }
 }

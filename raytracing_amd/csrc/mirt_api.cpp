@@ -614,6 +614,7 @@ struct Job {
   uint32_t* hit_type = nullptr;
   uint32_t* hit_object = nullptr;
   float* hit_t = nullptr;
+  float4* hit_records = nullptr;
   uint64_t want_pool = 0;
   uint32_t flags = 0;
   bool fixed_workspace = false;  // work in the library's fixed workspace: no allocation of any kind
@@ -725,6 +726,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.hit_type = job.hit_type;
   args.hit_object = job.hit_object;
   args.hit_t = job.hit_t;
+  args.hit_records = job.hit_records;
   // (pageable source: the copy has left `args` by the time the call returns)
   MIRT_HIP(ctx, hipMemcpyAsync(ws.args, &args, sizeof(args), hipMemcpyHostToDevice, stream));
   MIRT_HIP(ctx, launch_render(ws.args, count_work, cfg, stream));
@@ -872,8 +874,9 @@ int mirt_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   return MIRT_OK;
 }
 
-int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays_device, size_t n, uint64_t seed,
-                      uint32_t* type_index_device, uint32_t* object_index_device, float* t_device, void* stream) {
+static int trace_device_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays_device, size_t n,
+                             uint64_t seed, uint32_t* type_index_device, uint32_t* object_index_device,
+                             float* t_device, float4* records_device, void* stream) {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!scene || (n && (!rays_device || !type_index_device || !object_index_device || !t_device)))
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
@@ -890,7 +893,45 @@ int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray
   job.hit_type = type_index_device;
   job.hit_object = object_index_device;
   job.hit_t = t_device;
+  job.hit_records = records_device;
   return run_job(ctx, scene, job, (hipStream_t)stream /* NULL: the null stream */, nullptr);
+}
+
+int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays_device, size_t n, uint64_t seed,
+                      uint32_t* type_index_device, uint32_t* object_index_device, float* t_device, void* stream) {
+  return trace_device_impl(ctx, scene, rays_device, n, seed, type_index_device, object_index_device, t_device, nullptr,
+                           stream);
+}
+
+static int check_ray_times(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n) {
+  if (scene->has_moving)
+    for (size_t i = 0; i < n; ++i)
+      if (!(rays[i].time >= scene->time0 && rays[i].time <= scene->time1))
+        return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "ray time outside the scene's time range");
+  return MIRT_OK;
+}
+
+int mirt_trace_records(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,
+                       mirt_hit_record* records) {
+  static_assert(sizeof(mirt_hit_record) == 64, "a hit record is four quads");
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!scene || (n && (!rays || !records))) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n == 0) return MIRT_OK;
+  const int tr = check_ray_times(ctx, scene, rays, n);
+  if (tr != MIRT_OK) return tr;
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceBuffer d_rays, d_ti, d_oi, d_t, d_rec;
+  MIRT_HIP(ctx, d_rays.ensure(n * sizeof(mirt_ray)));
+  MIRT_HIP(ctx, d_ti.ensure(n * 4));
+  MIRT_HIP(ctx, d_oi.ensure(n * 4));
+  MIRT_HIP(ctx, d_t.ensure(n * 4));
+  MIRT_HIP(ctx, d_rec.ensure(n * sizeof(mirt_hit_record)));
+  MIRT_HIP(ctx, hipMemcpy(d_rays.ptr, rays, n * sizeof(mirt_ray), hipMemcpyHostToDevice));
+  const int rc = trace_device_impl(ctx, scene, d_rays.as<mirt_ray>(), n, seed, d_ti.as<uint32_t>(), d_oi.as<uint32_t>(),
+                                   d_t.as<float>(), d_rec.as<float4>(), nullptr);
+  if (rc != MIRT_OK) return rc;
+  MIRT_HIP(ctx, hipMemcpy(records, d_rec.ptr, n * sizeof(mirt_hit_record), hipMemcpyDeviceToHost));
+  return MIRT_OK;
 }
 
 int mirt_trace_primary(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,
@@ -899,10 +940,8 @@ int mirt_trace_primary(mirt_context* ctx, const mirt_scene* scene, const mirt_ra
   if (!scene || (n && (!rays || !type_index || !object_index || !t)))
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   if (n == 0) return MIRT_OK;
-  if (scene->has_moving)
-    for (size_t i = 0; i < n; ++i)
-      if (!(rays[i].time >= scene->time0 && rays[i].time <= scene->time1))
-        return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "ray time outside the scene's time range");
+  const int tr = check_ray_times(ctx, scene, rays, n);
+  if (tr != MIRT_OK) return tr;
   MIRT_HIP(ctx, hipSetDevice(ctx->device));
   DeviceBuffer d_rays, d_ti, d_oi, d_t;
   MIRT_HIP(ctx, d_rays.ensure(n * sizeof(mirt_ray)));

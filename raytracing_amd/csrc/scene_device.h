@@ -250,11 +250,12 @@ struct RenderArgs {
   // that graze a large scene for thousands of steps do not hold up the round for everyone; 0 = to the end.
   float chunk_len;
   // Tracing caller-supplied rays instead of rendering (rays != nullptr): rc.total_paths rays come from `rays`,
-  // each is walked once, and what ray g hit goes to hit_type[g], hit_object[g], hit_t[g].
+  // each is walked once, and what ray g hit goes to hit_type[g], hit_object[g], hit_t[g] (and hit_records).
   const mirt_ray* rays;
   uint32_t* hit_type;
   uint32_t* hit_object;
   float* hit_t;
+  float4* hit_records;  // optional: four quads per ray, the layout of mirt_hit_record
 };
 // `args` is a device pointer; the caller keeps it unchanged until the kernel has finished.
 hipError_t launch_render(const RenderArgs* args, bool count_work, const RenderConfig& cfg, hipStream_t stream);

@@ -44,6 +44,8 @@ def lib():
                                      C.c_void_p, C.c_void_p]
     L.oracle_scene_hit_records.restype = C.c_int
     L.oracle_scene_hit_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
+    L.oracle_scene_hit_records_full.restype = C.c_int
+    L.oracle_scene_hit_records_full.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
     L.oracle_philox.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.oracle_kat_hit.restype = C.c_int
     L.oracle_kat_hit.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
@@ -53,6 +55,21 @@ def lib():
     L.oracle_kat_encode.argtypes = [C.c_float, C.c_uint32]
     L.oracle_kat_aabb_hit.restype = C.c_int
     L.oracle_kat_aabb_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    L.oracle_kat_wrapped_sphere.restype = C.c_int
+    L.oracle_kat_wrapped_sphere.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    L.oracle_kat_medium.restype = C.c_int
+    L.oracle_kat_medium.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_uint32,
+                                    C.c_void_p]
+    L.oracle_kat_pdf_value.restype = C.c_float
+    L.oracle_kat_pdf_value.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_kat_mixture_value.restype = C.c_float
+    L.oracle_kat_mixture_value.argtypes = [C.c_void_p] * 4
+    L.oracle_kat_perlin.restype = C.c_float
+    L.oracle_kat_perlin.argtypes = [C.c_void_p] * 5 + [C.c_uint32]
+    L.oracle_kat_image_texel.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+    L.oracle_kat_sphere_uv.argtypes = [C.c_void_p, C.c_void_p]
+    L.oracle_kat_checker_is_odd.restype = C.c_int
+    L.oracle_kat_checker_is_odd.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -130,6 +147,22 @@ class Scene:
         return out
 
 
+RECORD_DTYPE = np.dtype([("point", np.float32, 3), ("t", np.float32), ("normal", np.float32, 3),
+                         ("front_face", np.uint32), ("u", np.float32), ("v", np.float32), ("type_index", np.uint32),
+                         ("object_index", np.uint32), ("color", np.float32, 3), ("last", np.uint32)])
+
+
+def hit_records_full(scene, rays, seed=7):
+    """Record-level view of every ray's closest hit, in the layout of the device library's mirt_hit_record
+    (`last` = 1 for a hit here, the material kind there)."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 7)
+    out = np.zeros(rays.shape[0], RECORD_DTYPE)
+    rc = scene.L.oracle_scene_hit_records_full(scene.h, _ptr(rays), rays.shape[0], seed, _ptr(out))
+    if rc != 0:
+        raise RuntimeError("oracle hit_records_full failed")
+    return out
+
+
 def encode(sums, spp):
     sums = np.ascontiguousarray(sums, np.float32)
     out = np.zeros(sums.shape, np.uint8)
@@ -151,6 +184,59 @@ def kat_hit(kind, params, ray, t_min=0.001, t_max=float("inf")):
     out = np.zeros(10, np.float32)
     ok = lib().oracle_kat_hit(kind, _ptr(p), _ptr(r), t_min, t_max, _ptr(out))
     return (ok == 1), out
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def kat_wrapped_sphere(wrapper, sphere, ray, offset=(0, 0, 0), angle=0.0, t_min=0.001, t_max=float("inf")):
+    """wrapper: 1 Translate, 2 Rotate (degrees about y), 3 FlipFace, 4 Translate(Rotate(.)); out as kat_hit."""
+    wp, p, r, out = _f(list(offset) + [angle]), _f(sphere), _f(ray), np.zeros(10, np.float32)
+    ok = lib().oracle_kat_wrapped_sphere(wrapper, _ptr(wp), _ptr(p), _ptr(r), t_min, t_max, _ptr(out))
+    assert ok >= 0
+    return ok == 1, out
+
+
+def kat_medium(sphere, density, ray, seed=0, pixel=0, t_min=0.001, t_max=float("inf")):
+    p, r, out = _f(sphere), _f(ray), np.zeros(10, np.float32)
+    ok = lib().oracle_kat_medium(_ptr(p), density, _ptr(r), t_min, t_max, seed, pixel, _ptr(out))
+    return ok == 1, out
+
+
+def kat_pdf_value(kind, params, origin, direction):
+    p, o, d = _f(params), _f(origin), _f(direction)
+    return float(lib().oracle_kat_pdf_value(kind, _ptr(p), _ptr(o), _ptr(d)))
+
+
+def kat_mixture_value(rect, origin, normal, direction):
+    a, o, n, d = _f(rect), _f(origin), _f(normal), _f(direction)
+    return float(lib().oracle_kat_mixture_value(_ptr(a), _ptr(o), _ptr(n), _ptr(d)))
+
+
+def kat_perlin(vec, perm_x, perm_y, perm_z, p, depth=0):
+    v = _f(vec).reshape(256, 3)
+    px, py, pz = (np.ascontiguousarray(a, np.uint32) for a in (perm_x, perm_y, perm_z))
+    q = _f(p)
+    return float(lib().oracle_kat_perlin(_ptr(v), _ptr(px), _ptr(py), _ptr(pz), _ptr(q), depth))
+
+
+def kat_image_texel(image, u, v):
+    img = np.ascontiguousarray(image, np.uint8)
+    out = np.zeros(3, np.float32)
+    lib().oracle_kat_image_texel(_ptr(img), img.shape[1], img.shape[0], u, v, _ptr(out))
+    return out
+
+
+def kat_sphere_uv(p):
+    q, out = _f(p), np.zeros(2, np.float32)
+    lib().oracle_kat_sphere_uv(_ptr(q), _ptr(out))
+    return float(out[0]), float(out[1])
+
+
+def kat_checker_is_odd(p):
+    q = _f(p)
+    return lib().oracle_kat_checker_is_odd(_ptr(q)) == 1
 
 
 def kat_onb(n):

@@ -223,3 +223,227 @@ def test_max_depth_zero_is_black_and_miss_is_background():
     # a ray into the sky returns the background (renderer.rs:187-189): top row of the image, depth 1
     rgb, sums, _ = s.render(32, 18, 4, depth=1)
     assert np.allclose(sums[0] / 4, 0.8, atol=1e-6)
+
+
+# ---- wrappers (transforms.rs) ---------------------------------------------------------------------------------
+
+def test_translate_recomputes_the_face_flag_against_the_forwarded_normal():
+    # transforms.rs:15-24.  Sphere r=2 at the object-space origin, moved by (10,0,0); a ray from its centre along +x:
+    # the sphere reports t=2, outward (1,0,0), back face, normal forwarded to (-1,0,0) (hittable.rs:28-35).
+    # Translate then sets front_face = dot(direction, normal) < 0 with that forwarded normal: (1,0,0).(-1,0,0) < 0
+    # -> TRUE, and leaves the normal alone.  (The bare sphere says back face: test_sphere_second_root_from_inside.)
+    ok, out = O.kat_wrapped_sphere(1, [0, 0, 0, 2], [10, 0, 0, 1, 0, 0, 0], offset=(10, 0, 0))
+    assert ok and out[0] == 2.0 and out[3] == 1.0
+    assert tuple(out[4:7]) == (12.0, 0.0, 0.0)            # point moved back by the offset (:18)
+    assert tuple(out[7:10]) == (-1.0, 0.0, 0.0)
+    # from outside nothing changes: front face, outward normal
+    ok, out = O.kat_wrapped_sphere(1, [0, 0, 0, 2], [5, 0, 0, 1, 0, 0, 0], offset=(10, 0, 0))
+    assert ok and out[0] == 3.0 and out[3] == 1.0 and tuple(out[4:7]) == (8.0, 0.0, 0.0)
+    assert tuple(out[7:10]) == (-1.0, 0.0, 0.0)
+
+
+def test_rotate_tests_the_face_with_the_object_space_direction_against_the_world_space_normal():
+    # transforms.rs:81-110 at 90 degrees (sin = 1, cos = cos_f32(pi/2) ~ -4.4e-8).  World -> object: x' = c x - s z,
+    # z' = s x + c z (:85-89), so the world ray o=(2,0,-5), d=(-1,0,1) becomes o'=(5,0,2), d'=(-1,0,-1).  Against the
+    # sphere at (2,0,0), r=1: os=(3,0,2), a=2, half_b=-5, c=12, disc=1, root=(5-1)/2=2 -> point (3,0,0), outward
+    # (1,0,0), front (d'.n = -1).  Back to the world (:97-101): point (0,0,-3), normal (0,0,-1); the world ray hits
+    # that side from outside (d.n = -1): a front face.  But the face test (:104) takes d' (object space) against
+    # the world-space normal: (-1,0,-1).(0,0,-1) = +1, not < 0, so the hit is reported as a BACK face and the
+    # normal is negated to (0,0,+1).
+    ok, out = O.kat_wrapped_sphere(2, [2, 0, 0, 1], [2, 0, -5, -1, 0, 1, 0], angle=90.0)
+    assert ok and abs(out[0] - 2.0) < 1e-6
+    assert out[3] == 0.0
+    assert np.allclose(out[4:7], [0, 0, -3], atol=1e-6)
+    assert np.allclose(out[7:10], [0, 0, 1], atol=1e-6)
+    # at 0 degrees Rotate is the identity and the flag is the sphere's own
+    ok, out = O.kat_wrapped_sphere(2, [0, 0, -3, 1], [0, 0, -8, 0, 0, 1, 0], angle=0.0)
+    assert ok and out[0] == 4.0 and out[3] == 1.0 and tuple(out[7:10]) == (0.0, 0.0, -1.0)
+    # 180 degrees: d' = -d, the normal turns with it, dot(d', n_world) = dot(-d, n_world) > 0 for a front hit:
+    # every front hit is reported as a back face with the normal flipped along the ray
+    ok, out = O.kat_wrapped_sphere(2, [0, 0, 3, 1], [0, 0, -8, 0, 0, 1, 0], angle=180.0)   # world centre (0,0,-3)
+    assert ok and abs(out[0] - 4.0) < 1e-5 and out[3] == 0.0 and np.allclose(out[7:10], [0, 0, 1], atol=1e-6)
+
+
+def test_translate_of_rotate_as_the_cornell_box_nests_them():
+    # cornel_box.rs:90-99: Translate(Rotate(obj, angle), offset).  The case above moved by (0,0,10): Translate
+    # hands Rotate the ray o - offset; Rotate reports back face, normal (0,0,1); Translate adds the offset to the
+    # point and recomputes the flag with the world direction against that normal: (-1,0,1).(0,0,1) > 0 -> back face
+    # stays, normal untouched.
+    ok, out = O.kat_wrapped_sphere(4, [2, 0, 0, 1], [2, 0, 5, -1, 0, 1, 0], offset=(0, 0, 10), angle=90.0)
+    assert ok and abs(out[0] - 2.0) < 1e-5 and out[3] == 0.0
+    assert np.allclose(out[4:7], [0, 0, 7], atol=1e-5) and np.allclose(out[7:10], [0, 0, 1], atol=1e-6)
+    # 180 degrees inside a Translate: Rotate says back face with the normal along the ray (previous test), and
+    # Translate's own test against that normal, (0,0,1).(0,0,1) > 0, agrees
+    ok, out = O.kat_wrapped_sphere(4, [0, 0, 3, 1], [5, 0, -8, 0, 0, 1, 0], offset=(5, 0, 0), angle=180.0)
+    assert ok and abs(out[0] - 4.0) < 1e-5 and out[3] == 0.0 and np.allclose(out[7:10], [0, 0, 1], atol=1e-6)
+
+
+def test_flip_face_toggles_the_flag_only():
+    # transforms.rs:197-205
+    ok, out = O.kat_wrapped_sphere(3, [0, 0, 0, 1], [0, 0, -5, 0, 0, 1, 0])
+    assert ok and out[0] == 4.0 and out[3] == 0.0 and tuple(out[7:10]) == (0.0, 0.0, -1.0)
+
+
+# ---- constant medium (transforms.rs:133-180) -----------------------------------------------------------------
+
+def media_draw(seed, pixel):
+    """Draw 0 of the media stream of (pixel, sample 0, bounce 0): Philox counter (pixel, 0, stage 1, block 0)."""
+    word = O.philox([pixel, 0, 1, 0], [seed & 0xFFFFFFFF, seed >> 32])[0]
+    return F(word >> 8) * F(1.0 / 16777216.0)
+
+
+def test_constant_medium_free_flight():
+    # Unit sphere at the origin, ray o=(0,0,-5), d=(0,0,2): boundary hits at t=2 and t=3 (:135-136), |d|=2, so
+    # distance_inside = (3-2)*2 = 2 (:152-153).  hit_distance = -1/density * log2(xi) (:154 -- log2, not ln);
+    # accepted when <= 2, then t = 2 + hit_distance/2, normal (1,0,0), front face, u=v=0 (:160-172).
+    sphere, ray = [0, 0, 0, 1], [0, 0, -5, 0, 0, 2, 0]
+    hits = misses = 0
+    for pixel in range(40):
+        xi = media_draw(9, pixel)
+        density = F(0.8)
+        neg_inv = F(-1.0) / density
+        hit_distance = neg_inv * F(math.log2(float(xi))) if xi > 0 else F(np.inf)
+        ok, out = O.kat_medium(sphere, float(density), ray, seed=9, pixel=pixel)
+        assert ok == bool(hit_distance <= F(2.0))
+        if ok:
+            hits += 1
+            assert abs(out[0] - (2.0 + float(hit_distance) / 2.0)) < 2e-6
+            assert tuple(out[7:10]) == (1.0, 0.0, 0.0) and out[3] == 1.0 and out[1] == 0.0 and out[2] == 0.0
+            assert np.allclose(out[4:7], [0, 0, -5 + 2 * out[0]], atol=1e-5)
+        else:
+            misses += 1
+    assert hits > 5 and misses > 5
+
+
+def test_constant_medium_clamps_to_the_callers_range():
+    sphere = [0, 0, 0, 1]
+    # t_max in front of the boundary's entry: hit1.t=2 >= hit2.t=min(3, 1.5) -> none (:140-146)
+    for pixel in range(8):
+        ok, _ = O.kat_medium(sphere, 1e6, [0, 0, -5, 0, 0, 2, 0], seed=1, pixel=pixel, t_max=1.5)
+        assert not ok
+    # origin inside: hit1.t = -0.5 is raised to t_min = 0.001 (:137-139); a very dense medium scatters at once
+    ok, out = O.kat_medium(sphere, 1e9, [0, 0, 0, 0, 0, 2, 0], seed=1, pixel=0)
+    assert ok and abs(out[0] - 0.001) < 1e-6
+    # a ray that misses the boundary
+    ok, _ = O.kat_medium(sphere, 1e9, [0, 3, -5, 0, 0, 2, 0], seed=1, pixel=0)
+    assert not ok
+
+
+def test_constant_medium_negative_zero_density():
+    # ConstantMedium::new: neg_inv_density = -1.0 / -0.0 = +inf (:128); hit_distance = +inf * log2(xi) = -inf for
+    # xi in (0,1); `-inf > distance_inside` is false, so the medium always scatters, at t = hit1.t + (-inf)/|d| = -inf
+    ok, out = O.kat_medium([0, 0, 0, 1], -0.0, [0, 0, -5, 0, 0, 2, 0], seed=3, pixel=1)
+    assert 0 < media_draw(3, 1) < 1
+    assert ok and out[0] == -np.inf and out[3] == 1.0
+
+
+# ---- light pdfs (objects.rs:82-94, 292-301; pdf.rs:81-83) ---------------------------------------------------------
+
+def test_xz_rect_pdf_value_closed_form():
+    rect = [0, 2, 0, 4, 1]                      # area 8, plane y = 1
+    # straight up from (1,0,2) with |d| = 2: t = 0.5, t^2 |d|^2 = 1, cosine 1 -> 1/8
+    assert O.kat_pdf_value(2, rect, [1, 0, 2], [0, 2, 0]) == 0.125
+    # oblique d = (0,1,1) from (1,0,1): t = 1, hits (1,1,2); t^2 |d|^2 = 2, cosine = 1/sqrt 2 -> 2 sqrt 2 / 8
+    assert abs(O.kat_pdf_value(2, rect, [1, 0, 1], [0, 1, 1]) - 2 * math.sqrt(2) / 8) < 1e-7
+    # pointing away / missing the rect / starting on it (t < 0.0001)
+    assert O.kat_pdf_value(2, rect, [1, 0, 2], [0, -1, 0]) == 0.0
+    assert O.kat_pdf_value(2, rect, [5, 0, 2], [0, 1, 0]) == 0.0
+    assert O.kat_pdf_value(2, rect, [1, 1, 2], [0, 1, 0]) == 0.0
+    # the edge still counts (strict comparisons, objects.rs:268-271)
+    assert O.kat_pdf_value(2, rect, [2, 0, 4], [0, 1, 0]) == 0.125
+    # XYRect keeps the trait default (hittable.rs:52-54)
+    assert O.kat_pdf_value(1, rect, [1, 2, 0], [0, 0, 1]) == 0.0
+
+
+def test_sphere_pdf_value_closed_form():
+    # centre (0,0,3), r = 1 seen from the origin: cos_max = sqrt(1 - 1/9), pdf = 1 / (2 pi (1 - cos_max))
+    expect = 1.0 / (2 * math.pi * (1 - math.sqrt(1 - 1 / 9)))
+    assert abs(O.kat_pdf_value(0, [0, 0, 3, 1], [0, 0, 0], [0, 0, 1]) - expect) < 2e-6
+    assert abs(O.kat_pdf_value(0, [0, 0, 3, 1], [0, 0, 0], [0, 0, 5]) - expect) < 2e-6      # any length
+    assert O.kat_pdf_value(0, [0, 0, 3, 1], [0, 0, 0], [0, 1, 0]) == 0.0                     # misses the sphere
+    # from inside the sphere: 1 - r^2/d^2 < 0 -> NaN, as the reference computes it
+    assert math.isnan(O.kat_pdf_value(0, [0, 0, 3, 1], [0, 0, 3.5], [0, 0, 1]))
+
+
+def test_mixture_pdf_value_is_the_even_average():
+    rect = [0, 2, 0, 4, 1]
+    # light pdf 1/8 (above), cosine pdf cos/pi = 1/pi around the normal (0,1,0) -> (1/8 + 1/pi)/2
+    got = O.kat_mixture_value(rect, [1, 0, 2], [0, 1, 0], [0, 2, 0])
+    assert abs(got - 0.5 * (0.125 + 1 / math.pi)) < 1e-7
+    # below the horizon of the normal the cosine term is 0 (pdf.rs:25-32), the light term stays
+    got = O.kat_mixture_value(rect, [1, 0, 2], [0, -1, 0], [0, 2, 0])
+    assert abs(got - 0.0625) < 1e-7
+    # a direction that misses the light: cosine term only (45 degrees: cos = 1/sqrt 2)
+    got = O.kat_mixture_value(rect, [1.5, 0, 2], [0, 1, 0], [9, 9, 0])      # crosses y = 1 at x = 2.5
+    assert abs(got - 0.5 * (1 / math.sqrt(2)) / math.pi) < 1e-7
+
+
+# ---- Perlin noise with tables that can be followed by hand (perlin.rs:26-60, 75-93) ------------------------------
+
+def test_perlin_noise_and_turbulence_with_identity_tables():
+    ident = np.arange(256, dtype=np.uint32)
+    vec = np.zeros((256, 3), F)
+    vec[:, 0] = np.arange(256)                # gradient h = (h, 0, 0): the value names the lattice hash
+    # p = (3.25, 5, 9): i,j,k = 3,5,9; u = .25, v = w = 0 -> vv = ww = 0, only dj = dk = 0 contribute.
+    # uu = .25^2 (3 - .5) = .15625.  Hashes 3^5^9 = 15 and 4^5^9 = 8.
+    # noise = (1-uu) * 15 * u + uu * 8 * (u - 1) = .84375 * 3.75 - .15625 * 6 = 2.2265625   (exact in binary)
+    assert O.kat_perlin(vec, ident, ident, ident, [3.25, 5, 9]) == 2.2265625
+    # turb depth 2 adds 0.5 * noise(2p), 2p = (6.5, 10, 18): u = .5, uu = .5, hashes 6^10^18 = 30 and 7^10^18 = 31:
+    # .5 * 30 * .5 + .5 * 31 * (-.5) = -0.25 ; |2.2265625 - 0.125| = 2.1015625
+    assert O.kat_perlin(vec, ident, ident, ident, [6.5, 10, 18]) == -0.25
+    assert O.kat_perlin(vec, ident, ident, ident, [3.25, 5, 9], depth=2) == 2.1015625
+    # negative coordinates: floor(-0.75) = -1, (-1 & 255) = 255 and (0 & 255) = 0, u = .25
+    assert O.kat_perlin(vec, ident, ident, ident, [-0.75, 0, 0]) == 0.84375 * 255 * 0.25
+    # the three tables are combined by XOR, each indexed by its own axis
+    px = (ident + 1) & 255
+    # i = 3 -> perm_x[3] = 4, perm_x[4] = 5: hashes 4^5^9 = 8 and 5^5^9 = 9
+    assert O.kat_perlin(vec, px, ident, ident, [3.25, 5, 9]) == 0.84375 * 8 * 0.25 + 0.15625 * 9 * (-0.75)
+    # a gradient along y only shows through v
+    vy = np.zeros((256, 3), F)
+    vy[:, 1] = 1.0
+    assert O.kat_perlin(vy, ident, ident, ident, [3.25, 5, 9]) == 0.0
+    # v = .5: vv = .5 -> .5 * .5 + .5 * (-.5) = 0 ; v = .25 -> .84375 * .25 - .15625 * .75 = 0.09375
+    assert O.kat_perlin(vy, ident, ident, ident, [3, 5.25, 9]) == 0.09375
+
+
+# ---- image texture addressing (texture.rs:101-122), sphere (u, v) (objects.rs:17-28), checker (texture.rs:51-60) ----
+
+def test_image_texture_addressing():
+    img = np.zeros((2, 4, 3), np.uint8)        # 4 wide, 2 high; texel (i, j) = (10 i, 100 j, 255)
+    for j in range(2):
+        for i in range(4):
+            img[j, i] = (10 * i, 100 * j, 255)
+
+    def texel(u, v):
+        c = O.kat_image_texel(img, u, v)
+        assert c[2] == 1.0
+        return round(float(c[0]) * 255 / 10), round(float(c[1]) * 255 / 100)
+    assert texel(0.0, 1.0) == (0, 0)           # v is flipped: v = 1 is row 0, the top of the image
+    assert texel(0.0, 0.0) == (0, 1)           # v = 0 -> 1 * height = 2 -> clamped to the last row
+    assert texel(1.0, 1.0) == (3, 0)           # u = 1 -> 4 -> clamped to the last column
+    assert texel(0.5, 0.5) == (2, 1)           # .5 * 4 = 2 ; (1 - .5) * 2 = 1
+    assert texel(0.49, 0.51) == (1, 0)
+    assert texel(-3.0, 7.0) == (0, 0)          # clamped to [0,1] first
+    assert texel(9.0, -2.0) == (3, 1)
+    assert texel(float("nan"), 1.0) == (0, 0)  # f32::clamp keeps NaN; NaN as u32 = 0
+    c = O.kat_image_texel(img, 0.5, 1.0)
+    assert c[0] == F(1.0 / 255.0) * F(20.0)    # COLOR_SCALE * byte, in f32
+
+
+def test_sphere_uv_at_the_axes():
+    # u = (-atan2(z, x) + pi) / 2 pi, v = acos(-y) / pi
+    for p, u, v in (((1, 0, 0), 0.5, 0.5), ((-1, 0, 0), 0.0, 0.5), ((0, 0, 1), 0.25, 0.5), ((0, 0, -1), 0.75, 0.5),
+                    ((0, 1, 0), 0.5, 1.0), ((0, -1, 0), 0.5, 0.0)):
+        gu, gv = O.kat_sphere_uv(p)
+        assert abs(gu - u) < 1e-7 and abs(gv - v) < 1e-7, p
+    gu, gv = O.kat_sphere_uv([0.6, 0.0, 0.8])
+    assert abs(gu - (math.pi - math.atan2(0.8, 0.6)) / (2 * math.pi)) < 1e-7 and abs(gv - 0.5) < 1e-7
+
+
+def test_checker_sign_of_the_product_of_sines():
+    # sin(10x) sin(10y) sin(10z) < 0 -> odd.  10 * 0.1 = 1 rad: all positive -> even; one negative coordinate -> odd
+    assert not O.kat_checker_is_odd([0.1, 0.1, 0.1])
+    assert O.kat_checker_is_odd([-0.1, 0.1, 0.1])
+    assert not O.kat_checker_is_odd([-0.1, -0.1, 0.1])
+    assert O.kat_checker_is_odd([0.1, 0.1, 0.4])      # sin(4) < 0
+    assert not O.kat_checker_is_odd([0.0, 0.1, 0.1])  # product 0 is not < 0
