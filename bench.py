@@ -273,7 +273,11 @@ def main():
                        "rounds_per_step": iterations / max(1, a.steps)},
             "roofline": roofline, "work_models": models,
         }
-        if not a.no_cpu_baseline and world == 1:
+        if a.scene.startswith("synthetic") and scene.primitive_count() > 100000:
+            # the reference's containers test every object against every ray (world.rs:75-94, bvh.rs:92-145 with its
+            # always-true box test): hours per frame at this size, so no CPU figure is taken for such scenes
+            result["cpu_baseline"] = None
+        elif not a.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(a.scene, a.width, a.height, depth)
         else:
             result["cpu_baseline"] = None

@@ -288,6 +288,8 @@ typedef struct mirt_render_params {
   uint64_t seed;              /* Philox key */
   uint32_t path_pool;         /* paths in flight; 0 = library default */
   uint32_t flags;             /* MIRT_RENDER_* */
+  uint32_t first_row;         /* render only rows [first_row, first_row + n_rows) of the image, row 0 = top (the */
+  uint32_t n_rows;            /*   strips of renderer.rs:57-71); n_rows = 0: every row.  Buffers keep the full size. */
 } mirt_render_params;
 
 /* MIRT_KERNEL_RENDER: the one kernel that traces a whole mirt_render_accumulate call */
@@ -343,6 +345,17 @@ typedef struct mirt_hit_record {
  * no reference counterpart: the reference has no device. */
 int mirt_context_create(int device_id, mirt_context** out);
 void mirt_context_destroy(mirt_context* ctx);
+
+/* A context over several GPUs of one node: what Renderer::render's strip threads are on the CPU
+ * (renderer.rs:55-87).  mirt_scene_upload then keeps a copy of the scene on every device; mirt_render gives every
+ * device a share of the frame -- `row_bands` horizontal bands of rows times n_devices / row_bands sample ranges
+ * (row_bands must divide n_devices; 0 or 1 = sample ranges only, which balances best) -- with one host thread per
+ * device, sums the partial images on device_ids[0] over the GPUs' links and encodes there.  Images do not depend on
+ * the split (same Philox streams; only the order of the f32 sums differs).  The entry points that take device
+ * pointers (mirt_render_accumulate, mirt_resolve, mirt_trace_*) run on device_ids[0].  n_devices = 1 is
+ * mirt_context_create.  A device may be listed more than once (its shares then run side by side on it). */
+int mirt_context_create_multi(const int* device_ids, int n_devices, uint32_t row_bands, mirt_context** out);
+int mirt_context_device_count(const mirt_context* ctx);
 
 /* Message of the last failed call on `ctx` (or of the last failed
  * mirt_context_create when ctx is NULL).  Valid until the next call. */

@@ -133,7 +133,8 @@ class Camera(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples_per_pixel", C.c_uint32),
                 ("first_sample", C.c_uint32), ("max_depth", C.c_uint32), ("background", C.c_float * 3),
-                ("seed", C.c_uint64), ("path_pool", C.c_uint32), ("flags", C.c_uint32)]
+                ("seed", C.c_uint64), ("path_pool", C.c_uint32), ("flags", C.c_uint32),
+                ("first_row", C.c_uint32), ("n_rows", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -160,7 +161,7 @@ class Ray(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("direction", C.c_float * 3), ("time", C.c_float)]
 
 
-MIRT_SYMBOLS = ["mirt_context_create", "mirt_context_destroy", "mirt_last_error", "mirt_scene_upload",
+MIRT_SYMBOLS = ["mirt_context_create", "mirt_context_create_multi", "mirt_context_device_count", "mirt_context_destroy", "mirt_last_error", "mirt_scene_upload",
                 "mirt_scene_destroy", "mirt_render", "mirt_render_accumulate", "mirt_render_accumulate_static",
                 "mirt_static_workspace_paths", "mirt_resolve",
                 "mirt_trace_primary", "mirt_trace_records", "mirt_trace_device", "mirt_version"]
@@ -188,6 +189,10 @@ def mirt():
     vp = C.c_void_p
     L.mirt_context_create.restype = C.c_int
     L.mirt_context_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mirt_context_create_multi.restype = C.c_int
+    L.mirt_context_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_uint32, C.POINTER(vp)]
+    L.mirt_context_device_count.restype = C.c_int
+    L.mirt_context_device_count.argtypes = [vp]
     L.mirt_context_destroy.argtypes = [vp]
     L.mirt_last_error.restype = C.c_char_p
     L.mirt_last_error.argtypes = [vp]
@@ -247,6 +252,11 @@ def examples():
                                                C.POINTER(Stats)]
     L.rt_example_resolve.restype = C.c_int
     L.rt_example_resolve.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.rt_lowered_open.restype = vp
+    L.rt_lowered_open.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p]
+    L.rt_lowered_close.argtypes = [vp]
+    L.rt_lowered_upload.restype = C.c_int
+    L.rt_lowered_upload.argtypes = [vp, vp, C.POINTER(vp)]
     L.rt_example_trace.restype = C.c_int
     L.rt_example_trace.argtypes = [vp, vp, C.c_size_t, C.c_uint64, vp, vp, vp]
     _examples = L

@@ -14,6 +14,7 @@
 // the reference.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -979,7 +980,9 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
   const V3 hor = v3(A->rc.cam.horizontal[0], A->rc.cam.horizontal[1], A->rc.cam.horizontal[2]);
   const V3 ver = v3(A->rc.cam.vertical[0], A->rc.cam.vertical[1], A->rc.cam.vertical[2]);
   const float lens_radius = A->rc.cam.lens_radius, time0 = A->rc.cam.time0, time1 = A->rc.cam.time1;
-  const uint32_t pixels = width * height;
+  // the rows this call renders (all of them unless the caller asked for a band), y counted upwards
+  const uint32_t band_y0 = A->rc.band_y0, band_rows = A->rc.band_rows;
+  const uint32_t pixels = width * band_rows;
   const FastDiv by_pixels{A->rc.by_pixels.m, A->rc.by_pixels.sh1, A->rc.by_pixels.sh2};
   const FastDiv by_groups{A->rc.by_groups.m, A->rc.by_groups.sh1, A->rc.by_groups.sh2};
   const FastDiv by_band{A->rc.by_band.m, A->rc.by_band.sh1, A->rc.by_band.sh2};
@@ -1004,7 +1007,8 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
       in_pass = ((scaled - fast_div(scaled, by_groups) * n_groups) << 6) | (in_pass & 63u);
     }
     uint32_t x, y;
-    pixel_of(in_pass, width, height, by_band, x, y);
+    pixel_of(in_pass, width, band_rows, by_band, x, y);
+    y += band_y0;
     const uint32_t pixel = y * width + x;
     const uint32_t sample = first_sample + pass;
     Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, key0, key1);
@@ -1693,6 +1697,25 @@ __global__ void k_resolve(const float* __restrict__ rgb_sum, uint32_t n_values, 
   rgb24[i] = out;
 }
 
+// dst += src over n_values floats (the partial images of the GPUs of one context, summed on the first one)
+__global__ void k_add(float* __restrict__ dst, const float* __restrict__ src, size_t n_values) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t quads = n_values / 4;
+  const bool aligned = (((uintptr_t)dst | (uintptr_t)src) & 15u) == 0;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (aligned) {
+    for (size_t q = i; q < quads; q += stride) {
+      float4 a = reinterpret_cast<float4*>(dst)[q];
+      const float4 b = reinterpret_cast<const float4*>(src)[q];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      reinterpret_cast<float4*>(dst)[q] = a;
+    }
+    for (size_t k = quads * 4 + i; k < n_values; k += stride) dst[k] += src[k];
+  } else {
+    for (size_t k = i; k < n_values; k += stride) dst[k] += src[k];
+  }
+}
+
 }  // namespace
 
 // ---- the fixed workspace ------------------------------------------------------------------
@@ -1784,6 +1807,13 @@ hipError_t launch_render(const RenderArgs* args, bool count_work, const RenderCo
     return count_work ? launch_render_as<true, true>(args, cfg, stream) : launch_render_as<false, true>(args, cfg, stream);
   }
   return count_work ? launch_render_as<true, false>(args, cfg, stream) : launch_render_as<false, false>(args, cfg, stream);
+}
+
+void launch_add(float* dst, const float* src, size_t n_values, hipStream_t stream) {
+  const uint32_t block = 256;
+  const size_t quads = n_values / 4;
+  const uint32_t grid = (uint32_t)std::min<size_t>((quads + block - 1) / block + 1, 1u << 16);
+  hipLaunchKernelGGL(k_add, dim3(grid), dim3(block), 0, stream, dst, src, n_values);
 }
 
 void launch_resolve(const float* rgb_sum, uint32_t n_values, uint32_t spp, uint8_t* rgb24, hipStream_t stream) {

@@ -12,6 +12,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mirt.h"
@@ -66,6 +67,12 @@ struct mirt_context {
   DeviceBuffer image_sum;
   DeviceBuffer image_rgb;
   void* static_workspace = nullptr;  // this device's copy of the library's fixed workspace (kernels.hip)
+  // A context over several GPUs: this one is the first device's; the others hang off it.  mirt_render gives every
+  // device a share of the frame and sums the partial images here, in one staging buffer per other device.
+  std::vector<mirt_context*> others;
+  std::vector<DeviceBuffer*> staging;
+  uint32_t row_bands = 1;
+  ~mirt_context() { for (DeviceBuffer* b : staging) delete b; }
 };
 
 struct mirt_scene {
@@ -77,6 +84,7 @@ struct mirt_scene {
   bool has_moving = false;
   uint32_t bvh_height = 0;
   size_t n_prims = 0;
+  std::vector<mirt_scene*> copies;  // the scene on the other devices of a context over several GPUs, in their order
 };
 
 namespace {
@@ -242,6 +250,48 @@ int mirt_version(void) { return 100; }
 
 const char* mirt_last_error(const mirt_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
+int mirt_context_create_multi(const int* device_ids, int n_devices, uint32_t row_bands, mirt_context** out) {
+  if (!out) return fail(nullptr, MIRT_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (!device_ids || n_devices < 1 || n_devices > 64)
+    return fail(nullptr, MIRT_ERR_INVALID_ARGUMENT, "between 1 and 64 devices, please");
+  if (row_bands == 0) row_bands = 1;
+  if ((uint32_t)n_devices % row_bands != 0)
+    return fail(nullptr, MIRT_ERR_INVALID_ARGUMENT, "row_bands must divide the number of devices");
+  mirt_context* first = nullptr;
+  int rc = mirt_context_create(device_ids[0], &first);
+  if (rc != MIRT_OK) return rc;
+  first->row_bands = row_bands;
+  for (int k = 1; k < n_devices; ++k) {
+    mirt_context* other = nullptr;
+    rc = mirt_context_create(device_ids[k], &other);
+    if (rc != MIRT_OK) {
+      const std::string why = g_create_error;
+      mirt_context_destroy(first);
+      return fail(nullptr, rc, "device " + std::to_string(device_ids[k]) + ": " + why);
+    }
+    first->others.push_back(other);
+    first->staging.push_back(new DeviceBuffer());
+    if (other->device != first->device) {
+      // direct copies over the GPUs' links where the platform allows them (already enabled is fine; without peer
+      // access hipMemcpyPeer still works, through the host)
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, first->device, other->device) == hipSuccess && can) {
+        (void)hipSetDevice(first->device);
+        (void)hipDeviceEnablePeerAccess(other->device, 0);
+        (void)hipSetDevice(other->device);
+        (void)hipDeviceEnablePeerAccess(first->device, 0);
+        (void)hipGetLastError();
+      }
+    }
+  }
+  (void)hipSetDevice(first->device);
+  *out = first;
+  return MIRT_OK;
+}
+
+int mirt_context_device_count(const mirt_context* ctx) { return ctx ? 1 + (int)ctx->others.size() : 0; }
+
 int mirt_context_create(int device_id, mirt_context** out) {
   if (!out) return fail(nullptr, MIRT_ERR_INVALID_ARGUMENT, "out is null");
   *out = nullptr;
@@ -277,17 +327,59 @@ int mirt_context_create(int device_id, mirt_context** out) {
 
 void mirt_context_destroy(mirt_context* ctx) {
   if (!ctx) return;
+  for (mirt_context* other : ctx->others) mirt_context_destroy(other);
+  ctx->others.clear();
   (void)hipSetDevice(ctx->device);
+  for (DeviceBuffer* b : ctx->staging) b->release();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
 void mirt_scene_destroy(mirt_context* ctx, mirt_scene* scene) {
+  if (!scene) return;
+  for (size_t k = 0; k < scene->copies.size(); ++k) {
+    if (ctx && k < ctx->others.size()) (void)hipSetDevice(ctx->others[k]->device);
+    delete scene->copies[k];
+  }
+  scene->copies.clear();
   if (ctx) (void)hipSetDevice(ctx->device);
   delete scene;
 }
 
+static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene** out);
+
 int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene** out) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!desc || !out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  // every device of the context gets its own copy, built side by side (one host thread per device)
+  const size_t n_others = ctx->others.size();
+  std::vector<mirt_scene*> copies(n_others, nullptr);
+  std::vector<int> status(n_others, MIRT_OK);
+  std::vector<std::thread> workers;
+  for (size_t k = 0; k < n_others; ++k)
+    workers.emplace_back([&, k] { status[k] = upload_one(ctx->others[k], desc, &copies[k]); });
+  mirt_scene* first = nullptr;
+  int rc = upload_one(ctx, desc, &first);
+  for (std::thread& w : workers) w.join();
+  for (size_t k = 0; k < n_others && rc == MIRT_OK; ++k)
+    if (status[k] != MIRT_OK) rc = fail(ctx, status[k], "device " + std::to_string(ctx->others[k]->device) + ": " + ctx->others[k]->error);
+  if (rc != MIRT_OK) {
+    for (size_t k = 0; k < n_others; ++k) {
+      (void)hipSetDevice(ctx->others[k]->device);
+      delete copies[k];
+    }
+    (void)hipSetDevice(ctx->device);
+    delete first;
+    return rc;
+  }
+  first->copies = std::move(copies);
+  (void)hipSetDevice(ctx->device);
+  *out = first;
+  return MIRT_OK;
+}
+
+static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene** out) {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!desc || !out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
@@ -769,12 +861,15 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   if ((uint64_t)p.first_sample + p.samples_per_pixel - 1 > MAX_SAMPLE_INDEX)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sample index beyond 2^24 - 1");
   if (p.max_depth > MAX_DEPTH_LIMIT) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "max_depth above 255");
+  const uint32_t n_rows = p.n_rows ? p.n_rows : p.height;
+  if ((p.n_rows == 0 && p.first_row != 0) || (uint64_t)p.first_row + n_rows > p.height)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "rows [first_row, first_row + n_rows) outside the image");
   if (!(camera->time0 <= camera->time1)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera time0 must be <= time1");
   if (scene->has_moving && (camera->time0 < scene->time0 || camera->time1 > scene->time1))
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera shutter interval outside the scene's time range");
   MIRT_HIP(ctx, hipSetDevice(ctx->device));
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  const uint64_t total = (uint64_t)p.width * p.height * p.samples_per_pixel;
+  const uint64_t total = (uint64_t)p.width * n_rows * p.samples_per_pixel;
   if (stats) stats->samples = total;
   if (p.max_depth == 0) return MIRT_OK;  // renderer.rs:147-149: every sample is black
 
@@ -783,13 +878,15 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   rc.cam = *camera;
   rc.width = p.width;
   rc.height = p.height;
+  rc.band_rows = n_rows;
+  rc.band_y0 = p.height - p.first_row - n_rows;  // the kernel counts y upwards from the bottom row (renderer.rs:216-217)
   rc.first_sample = p.first_sample;
   rc.max_depth = p.max_depth;
   rc.background[0] = p.background[0]; rc.background[1] = p.background[1]; rc.background[2] = p.background[2];
   rc.key0 = (uint32_t)p.seed;
   rc.key1 = (uint32_t)(p.seed >> 32);
   rc.total_paths = total;
-  rc.n_groups = (uint32_t)(((uint64_t)p.width * p.height) / 64);
+  rc.n_groups = (uint32_t)(((uint64_t)p.width * n_rows) / 64);
   rc.group_stride = 1;
   if (rc.n_groups > 1) {
     // about 61 strides across the frame, the nearest one that is coprime to the group count
@@ -799,7 +896,7 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
     while (stride > 1 && gcd(stride, rc.n_groups) != 1) --stride;
     rc.group_stride = (uint32_t)stride;
   }
-  rc.by_pixels = make_fastdiv(p.width * p.height);
+  rc.by_pixels = make_fastdiv(p.width * n_rows);
   rc.by_groups = make_fastdiv(std::max(1u, rc.n_groups));
   rc.by_band = make_fastdiv(p.width * 8u);
   rc.by_width = make_fastdiv(p.width);
@@ -812,6 +909,128 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   job.flags = p.flags;
   job.fixed_workspace = fixed_workspace;
   return run_job(ctx, scene, job, stream, stats);
+}
+
+// One share of a frame rendered by a context over several GPUs.
+struct Share {
+  uint32_t first_sample = 0, n_samples = 0;  // within the call's samples
+  uint32_t first_row = 0, n_rows = 0;        // within the call's rows
+};
+
+// The frame of `params` cut into one share per device: row_bands bands of rows times n / row_bands sample
+// ranges, device k taking band k / ranges, range k % ranges.  A share may be empty (fewer samples than ranges).
+std::vector<Share> cut_frame(const mirt_render_params& p, size_t n_devices, uint32_t row_bands) {
+  const uint32_t rows = p.n_rows ? p.n_rows : p.height;
+  uint32_t bands = std::max(1u, std::min(row_bands, rows));
+  const uint32_t ranges = (uint32_t)n_devices / bands;
+  std::vector<Share> shares(n_devices);
+  for (size_t k = 0; k < n_devices; ++k) {
+    const uint32_t band = (uint32_t)k / ranges, range = (uint32_t)k % ranges;
+    Share& sh = shares[k];
+    if (band >= bands) continue;  // (row_bands did not divide: the leftover devices idle)
+    // whole 8-row groups per band where there are enough rows (the kernel walks the image in 8-row bands)
+    const uint32_t groups = (rows + 7) / 8;
+    const uint32_t g0 = (uint32_t)((uint64_t)groups * band / bands), g1 = (uint32_t)((uint64_t)groups * (band + 1) / bands);
+    const uint32_t r0 = std::min(rows, g0 * 8), r1 = std::min(rows, g1 * 8);
+    sh.first_row = p.first_row + r0;
+    sh.n_rows = r1 - r0;
+    const uint32_t base = p.samples_per_pixel / ranges, extra = p.samples_per_pixel % ranges;
+    sh.first_sample = p.first_sample + range * base + std::min(range, extra);
+    sh.n_samples = base + (range < extra ? 1u : 0u);
+  }
+  return shares;
+}
+
+// mirt_render on a context over several GPUs: every device renders its share of the frame into its own sum
+// image (one host thread per device), the other devices' rows are copied to the first device over the GPUs'
+// links and added there.  ctx->image_sum holds the whole frame afterwards.
+int render_shared(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera, const mirt_render_params* params,
+                  mirt_stats* stats) {
+  if (!scene || !camera) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  const size_t n = 1 + ctx->others.size();
+  if (scene->copies.size() != ctx->others.size())
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "the scene was not uploaded through this context");
+  const mirt_render_params& p = *params;
+  if (p.samples_per_pixel == 0) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "samples_per_pixel must be positive");
+  const uint32_t rows = p.n_rows ? p.n_rows : p.height;
+  if ((p.n_rows == 0 && p.first_row != 0) || (uint64_t)p.first_row + rows > p.height)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "rows [first_row, first_row + n_rows) outside the image");
+  const std::vector<Share> shares = cut_frame(p, n, ctx->row_bands);
+  const size_t row_values = (size_t)p.width * 3;
+  const size_t n_values = row_values * p.height;
+  std::vector<int> status(n, MIRT_OK);
+  std::vector<mirt_stats> share_stats(n);
+  std::vector<char> copied(n, 0);
+  auto work = [&](size_t k) {
+    mirt_context* c = k == 0 ? ctx : ctx->others[k - 1];
+    const mirt_scene* sc = k == 0 ? scene : scene->copies[k - 1];
+    const Share& sh = shares[k];
+    std::memset(&share_stats[k], 0, sizeof(mirt_stats));
+    if (sh.n_samples == 0 || sh.n_rows == 0) return;
+    mirt_render_params q = p;
+    q.first_sample = sh.first_sample;
+    q.samples_per_pixel = sh.n_samples;
+    q.first_row = sh.first_row;
+    q.n_rows = sh.n_rows;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+      if (e == hipSuccess) return true;
+      status[k] = fail(c, e == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_DEVICE,
+                       std::string(what) + ": " + hipGetErrorString(e));
+      return false;
+    };
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return;
+    float* sums = ctx->image_sum.as<float>();
+    if (k != 0) {
+      if (!hip_ok(c->image_sum.ensure(n_values * sizeof(float)), "hipMalloc")) return;
+      sums = c->image_sum.as<float>();
+      // only the share's rows are touched
+      if (!hip_ok(hipMemsetAsync(sums + row_values * sh.first_row, 0, row_values * sh.n_rows * sizeof(float), c->stream),
+                  "hipMemsetAsync")) return;
+    }
+    status[k] = render_impl(c, sc, camera, &q, sums, c->stream, &share_stats[k]);
+    if (status[k] != MIRT_OK || k == 0) return;
+    // the share's rows, to the first device (the staging buffer was sized before the threads started)
+    const size_t bytes = row_values * sh.n_rows * sizeof(float);
+    if (!hip_ok(hipMemcpyPeer(ctx->staging[k - 1]->ptr, ctx->device, sums + row_values * sh.first_row, c->device, bytes),
+                "hipMemcpyPeer")) return;
+    copied[k] = 1;
+  };
+  for (size_t k = 1; k < n; ++k)
+    MIRT_HIP(ctx, ctx->staging[k - 1]->ensure(std::max<size_t>(16, row_values * shares[k].n_rows * sizeof(float))));
+  std::vector<std::thread> workers;
+  for (size_t k = 1; k < n; ++k) workers.emplace_back(work, k);
+  work(0);
+  for (std::thread& w : workers) w.join();
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  for (size_t k = 0; k < n; ++k)
+    if (status[k] != MIRT_OK) {
+      if (k != 0) ctx->error = "device " + std::to_string(ctx->others[k - 1]->device) + ": " + ctx->others[k - 1]->error;
+      return status[k];
+    }
+  for (size_t k = 1; k < n; ++k)
+    if (copied[k]) {
+      launch_add(ctx->image_sum.as<float>() + row_values * shares[k].first_row, ctx->staging[k - 1]->as<float>(),
+                 row_values * shares[k].n_rows, ctx->stream);
+      MIRT_HIP(ctx, hipGetLastError());
+    }
+  if (stats) {
+    // the whole job: work summed over the devices, times of the slowest one
+    *stats = share_stats[0];
+    for (size_t k = 1; k < n; ++k) {
+      const mirt_stats& o = share_stats[k];
+      stats->samples += o.samples; stats->segments += o.segments;
+      stats->nodes_visited += o.nodes_visited; stats->prims_tested += o.prims_tested;
+      stats->node_wave_steps += o.node_wave_steps; stats->prim_wave_steps += o.prim_wave_steps;
+      stats->render_ms = std::max(stats->render_ms, o.render_ms);
+      stats->iterations = std::max(stats->iterations, o.iterations);
+      for (int j = 0; j < MIRT_KERNEL_COUNT; ++j) {
+        stats->kernel_ms[j] = std::max(stats->kernel_ms[j], o.kernel_ms[j]);
+        stats->kernel_launches[j] += o.kernel_launches[j];
+      }
+      for (int j = 0; j < MIRT_PHASE_COUNT; ++j) stats->phase_cycles[j] += o.phase_cycles[j];
+    }
+  }
+  return MIRT_OK;
 }
 
 }  // namespace
@@ -859,7 +1078,9 @@ int mirt_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   MIRT_HIP(ctx, ctx->image_sum.ensure(n_values * sizeof(float)));
   MIRT_HIP(ctx, ctx->image_rgb.ensure(n_values));
   MIRT_HIP(ctx, hipMemsetAsync(ctx->image_sum.ptr, 0, n_values * sizeof(float), ctx->stream));
-  const int rc = render_impl(ctx, scene, camera, params, ctx->image_sum.as<float>(), ctx->stream, stats);
+  int rc;
+  if (ctx->others.empty()) rc = render_impl(ctx, scene, camera, params, ctx->image_sum.as<float>(), ctx->stream, stats);
+  else rc = render_shared(ctx, scene, camera, params, stats);
   if (rc != MIRT_OK) return rc;
   if (rgb24_out) {
     launch_resolve(ctx->image_sum.as<float>(), (uint32_t)n_values, params->samples_per_pixel,

@@ -183,17 +183,18 @@ inline FastDiv make_fastdiv(uint32_t d) {  // d >= 1
 struct RenderConst {
   mirt_camera cam;
   uint32_t width, height;
+  uint32_t band_y0, band_rows;  // the rows this call renders: y in [band_y0, band_y0 + band_rows), y = 0 at the bottom
   uint32_t first_sample;
   uint32_t max_depth;
   float background[3];
   uint32_t key0, key1;
   uint32_t pool;             // path records per buffer = N_REGIONS * region_cap
   uint32_t region_cap;       // slots per region; region s owns slots [s * region_cap, (s + 1) * region_cap)
-  uint64_t total_paths;      // width*height*samples_per_pixel of this call
+  uint64_t total_paths;      // width*band_rows*samples_per_pixel of this call
   // Order in which a pass walks the image: group j of 64 pixels (of the n_groups whole groups) is visited
   // as number (j * group_stride) % n_groups; group_stride is coprime to n_groups and their product < 2^32.
   uint32_t n_groups, group_stride;
-  FastDiv by_pixels, by_groups, by_band, by_width;  // / (width*height), / n_groups, / (8*width), / width
+  FastDiv by_pixels, by_groups, by_band, by_width;  // / (width*band_rows), / n_groups, / (8*width), / width
   // opt-in estimator changes (MIRT_RENDER_EVEN_LIGHTS, MIRT_RENDER_DROP_NONFINITE) and the jitter strata per axis
   // (0 = the reference's unstratified jitter)
   uint32_t estimator, strata;
@@ -260,6 +261,7 @@ struct RenderArgs {
 // `args` is a device pointer; the caller keeps it unchanged until the kernel has finished.
 hipError_t launch_render(const RenderArgs* args, bool count_work, const RenderConfig& cfg, hipStream_t stream);
 void launch_resolve(const float* rgb_sum, uint32_t n_values, uint32_t spp, uint8_t* rgb24, hipStream_t stream);
+void launch_add(float* dst, const float* src, size_t n_values, hipStream_t stream);  // dst += src
 
 
 }  // namespace mirt

@@ -112,6 +112,11 @@ void* rt_lowered_open(const char* name_c, uint64_t scene_seed, const char* asset
   return ok ? lo.release() : nullptr;
 }
 void rt_lowered_close(void* h) { delete static_cast<Lowered*>(h); }
+// Uploads the lowered scene through a context the caller made (e.g. one over several devices).
+int rt_lowered_upload(void* h, mirt_context* ctx, mirt_scene** out) {
+  const mirt_scene_desc desc = rt::make_desc(static_cast<Lowered*>(h)->L, 0.0f, 1.0f);
+  return mirt_scene_upload(ctx, &desc, out);
+}
 // out: spheres, moving spheres, rects, boxes, chains, chain ops, media, materials, textures, perlins, images,
 //      lights, light groups, lights_mode, top-level objects, 0
 void rt_lowered_counts(void* h, uint32_t out[16]) {

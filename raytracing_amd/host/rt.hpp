@@ -762,7 +762,15 @@ class DeviceScene {
   }
   template <class H, class LT>
   Status build(const H& hittable, const LT* lights, float time0, float time1, int device = 0) {
+    return build(hittable, lights, time0, time1, std::vector<int>{device}, 0);
+  }
+  // On several GPUs of the node (the device-side counterpart of the strip threads of renderer.rs:55-87): the scene
+  // is kept on every device and a render is shared out between them.
+  template <class H, class LT>
+  Status build(const H& hittable, const LT* lights, float time0, float time1, const std::vector<int>& devices,
+               uint32_t row_bands) {
     reset();
+    if (devices.empty()) return Status::err("no device given");
     const auto t0 = std::chrono::steady_clock::now();
     Lowerer L;
     lower_root(hittable, L);
@@ -770,7 +778,8 @@ class DeviceScene {
     if (!L.error.empty()) return Status::err("cannot lower scene: " + L.error);
     const mirt_scene_desc desc = make_desc(L, time0, time1);
     const auto t1 = std::chrono::steady_clock::now();
-    if (mirt_context_create(device, &ctx_) != MIRT_OK) return Status::err(mirt_last_error(nullptr));
+    if (mirt_context_create_multi(devices.data(), (int)devices.size(), row_bands, &ctx_) != MIRT_OK)
+      return Status::err(mirt_last_error(nullptr));
     const auto t2 = std::chrono::steady_clock::now();
     if (mirt_scene_upload(ctx_, &desc, &scene_) != MIRT_OK) {
       const std::string e = mirt_last_error(ctx_);
@@ -819,7 +828,7 @@ class Renderer {
   Status render(const H& hittable, const Camera& camera, const LT* lights) {
     const auto now = std::chrono::steady_clock::now();
     DeviceScene scene;
-    Status st = scene.build(hittable, lights, camera.time0, camera.time1, device_);
+    Status st = scene.build(hittable, lights, camera.time0, camera.time1, devices_, row_bands_);
     if (!st.is_ok()) return st;
     const mirt_camera cam = camera.lower();
     mirt_render_params p{};
@@ -861,7 +870,12 @@ class Renderer {
   const std::vector<uint8_t>& buffer() const { return buffer_; }
   const mirt_stats& stats() const { return stats_; }
   void set_seed(uint64_t s) { seed_ = s; }
-  void set_device(int d) { device_ = d; }
+  void set_device(int d) { devices_.assign(1, d); }
+  // Share every render out between these GPUs (row_bands bands of rows times sample ranges; 0 = sample ranges only).
+  void set_devices(const std::vector<int>& devices, uint32_t row_bands = 0) {
+    if (!devices.empty()) devices_ = devices;
+    row_bands_ = row_bands;
+  }
   // Opt-in estimator changes (MIRT_RENDER_EVEN_LIGHTS | MIRT_RENDER_DROP_NONFINITE | MIRT_RENDER_STRATA(n)); the
   // reference has none of them, and with 0 (the default) the render is the reference's estimator.
   void set_estimator(uint32_t flags) {
@@ -877,7 +891,8 @@ class Renderer {
   mirt_stats stats_{};
   uint64_t seed_ = 7;
   uint32_t estimator_ = 0;
-  int device_ = 0;
+  std::vector<int> devices_{0};
+  uint32_t row_bands_ = 0;
 };
 
 }  // namespace rt

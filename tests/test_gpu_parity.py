@@ -261,3 +261,29 @@ def test_rays_walked_in_stretches_find_the_same_hits(chunks, monkeypatch):
     assert np.allclose(sums[ok], whole_sums[ok], rtol=1e-4, atol=1e-5)
     assert float(O.psnr(rgb, orgb)) > 55.0
     assert abs(st["segments"] - oseg) <= max(8, oseg // 20000)
+
+
+def test_large_scene_library_defaults(scenes):
+    """A scene of more than 2^18 primitives with nothing overridden: the library picks the device (Morton order)
+    builder and walks camera paths in stretches.  Closest-hit ids and t bits of caller rays against the oracle's
+    bvh.rs tournament, then a same-seed render whose round count shows rays were carried from round to round."""
+    import os
+    for var in ("MIRT_BVH_BUILDER", "MIRT_CHUNKS", "MIRT_LEAF_MAX", "MIRT_REFILL_MIN", "MIRT_NODE_MIN"):
+        assert var not in os.environ
+    g, o = scenes("synthetic_bvh:256")                      # 513 x 513 cells
+    n = g.primitive_count()
+    assert n == o.object_count() and n >= 1 << 18
+    cam, _ = g.camera()
+    rays = np.concatenate([R.camera_rays(cam, 64, 36),
+                           random_rays(1200, [-250, 0.0, -250], [250, 3, 250], 31),      # inside the field
+                           random_rays(500, [-400, 0.01, -400], [400, 60, 400], 32)])     # above and around it
+    assert_same_hits(g, o, rays)
+    depth = 6
+    rgb, sums, st = g.render(32, 18, 1, depth=depth, seed=21)
+    assert not st["scene_in_lds"]
+    # every path of this frame is in flight at once, so whole-ray walks would take one round per bounce
+    assert st["iterations"] > depth, "no ray was carried over to another round"
+    orgb, osums, _ = o.render(32, 18, 1, depth=depth, seed=21)
+    ok = np.isfinite(osums).all(axis=2)
+    close = np.isclose(sums, osums, rtol=1e-4, atol=1e-5).all(axis=2)
+    assert np.mean(close[ok]) > 0.98                       # a libm rounding may flip a path
