@@ -335,7 +335,7 @@ struct Walk {
   V3 inv;
   float best_t;
   uint32_t best_ref, best_order, best_material, best_face, cur, sp;
-  float t_lo;  // the walk looks for hits from here on (renderer.rs:150's t_min, or where the last stretch ended)
+  uint32_t steps;  // tree steps and primitive tests this ray has taken in the current round
 };
 
 __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root) {
@@ -349,7 +349,7 @@ __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root)
   w.best_face = 0;
   w.cur = root;
   w.sp = 0;
-  w.t_lo = kTMin;
+  w.steps = 0;
 }
 
 // One step down the tree (w.cur must be an inner node): both child boxes are tested, the nearer one that
@@ -891,7 +891,8 @@ struct RenderShared {
   uint32_t shade_next;                  // next batch of 64 queue entries to hand out to a shading wave
   uint32_t late_next;                   // the same for the second shading pass
   uint32_t late_n[N_QUEUES];            // entries appended to each queue for the second shading pass
-  uint32_t pad[3];
+  uint32_t n_saved;                     // walks put aside this round (entries of the region's save area in use)
+  uint32_t pad[2];
   MediumEntry media[MIRT_MAX_MEDIA];
 };
 constexpr size_t SHARED_BYTES = (sizeof(RenderShared) + 255) / 256 * 256;  // the node array starts on an LDS row
@@ -987,7 +988,7 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
   const FastDiv by_groups{A->rc.by_groups.m, A->rc.by_groups.sh1, A->rc.by_groups.sh2};
   const FastDiv by_band{A->rc.by_band.m, A->rc.by_band.sh1, A->rc.by_band.sh2};
   const uint32_t strata = A->rc.strata;
-  const bool chunked = A->chunk_len > 0.0f;
+  const bool budgeted = A->step_budget != 0u;
   const FastDiv by_strata{A->rc.by_strata.m, A->rc.by_strata.sh1, A->rc.by_strata.sh2};
   const FastDiv by_cells{A->rc.by_cells.m, A->rc.by_cells.sh1, A->rc.by_cells.sh2};
   // path number = pass * pixels + place in the pass; the one long division is done once for the block
@@ -1041,7 +1042,7 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
     cur[4 * i] = make_float4(o.x, o.y, o.z, time);
     cur[4 * i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
     cur[4 * i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
-    if (chunked) cur[4 * i + 3] = make_float4(kTMin, 0.0f, 0.0f, 0.0f);  // where its first stretch starts
+    if (budgeted) cur[4 * i + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // no walk put aside: starts at the root
   }
 }
 
@@ -1070,9 +1071,15 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   const uint32_t root = RC::encode(A->sc.root_ref);
   const uint32_t refill_min = A->refill_min, node_min = A->node_min;
-  const float chunk_len = LDS_SCENE ? 0.0f : A->chunk_len;
-  const V3 root_lo = v3(A->sc.root_lo[0], A->sc.root_lo[1], A->sc.root_lo[2]);
-  const V3 root_hi = v3(A->sc.root_hi[0], A->sc.root_hi[1], A->sc.root_hi[2]);
+  // Scenes walked from global memory: a ray that has taken step_budget steps in this round is put aside -- its
+  // place in the tree (reference in hand, stack, closest hit so far) goes into the region's save area, the ray
+  // into QUEUE_CONTINUE -- and goes on from there in the next round, so that the few rays that graze a large scene
+  // for thousands of steps do not hold up the round for everyone.  The save area has two halves: the walks put
+  // aside in the last round are read from one while this round's are written to the other.
+  const uint32_t step_budget = LDS_SCENE ? 0u : A->step_budget;
+  const uint32_t save_cap = A->save_cap;
+  uint4* const saves_out = A->saves + (size_t)SAVE_QUADS * save_cap * (2u * region + (odd ? 1u : 0u));
+  const uint4* const saves_in = A->saves + (size_t)SAVE_QUADS * save_cap * (2u * region + (odd ? 0u : 1u));
   Work work{};
   uint32_t segments = 0;
   long long ts = 0;
@@ -1086,7 +1093,10 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   // are without work, then steps down the tree until (almost) every lane holds a leaf, then tests one
   // primitive in every lane that holds a leaf.
   for (;;) {
-    const bool done = slot != NO_SLOT && w.cur == RC::NONE;
+    // done: the closest hit is known.  spent: the round's budget is used up and the walk is put aside.
+    const bool finished = slot != NO_SLOT && w.cur == RC::NONE;
+    const bool spent = !LDS_SCENE && step_budget != 0u && slot != NO_SLOT && !finished && w.steps >= step_budget;
+    const bool done = finished || spent;
     const unsigned long long m_done = __ballot(done);
     const unsigned long long m_out = m_done | __ballot(slot == NO_SLOT);
     const uint32_t n_out = (uint32_t)__popcll(m_out);
@@ -1098,8 +1108,33 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       // those takes the wave's new rays off the region's list.
       int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_MISS : queue_of(w.best_material));
       if (q == QUEUE_LAMBERTIAN && ref_tag(w.best_ref) >= TAG_RECT) q = QUEUE_LAMBERTIAN_FLAT;
-      // nothing found in this stretch and the ray goes on (best_t is still where the stretch ends): next round
-      if (!LDS_SCENE && done && w.best_ref == REF_NONE && w.best_t < kInf) q = QUEUE_CONTINUE;
+      uint32_t saved_at = 0;  // 1 + entry of the save area
+      if (!LDS_SCENE && spent) {
+        // (one LDS atomic per wave; a full save area leaves the ray walking)
+        const unsigned long long m_spent = __ballot(1);
+        const uint32_t leader = (uint32_t)__ffsll((long long)m_spent) - 1u;
+        uint32_t first = 0;
+        if (lane == leader) first = atomicAdd(&sh.n_saved, (uint32_t)__popcll(m_spent));
+        first = __shfl(first, leader);
+        const uint32_t at = first + (uint32_t)__popcll(m_spent & ((1ull << lane) - 1ull));
+        if (at < save_cap) {
+          saved_at = at + 1u;
+          q = QUEUE_CONTINUE;
+          uint4* const sv = saves_out + (size_t)SAVE_QUADS * at;
+          sv[0] = make_uint4(w.cur, w.sp, w.best_ref, w.best_order);
+          sv[1] = make_uint4(__float_as_uint(w.best_t), w.best_material, w.best_face, 0u);
+          for (uint32_t k = 0; k < w.sp; k += 4u)
+            sv[2u + (k >> 2)] = make_uint4(stack[k * THREADS], stack[(k + 1u) * THREADS], stack[(k + 2u) * THREADS],
+                                           stack[(k + 3u) * THREADS]);
+        } else {
+          q = -1;
+          w.steps = 0;  // walks another budget's worth before it asks again
+        }
+      }
+      // the lanes that really leave (a spent walk stays when the save area is full) and the lanes to refill
+      const bool leaving = q >= 0;
+      const unsigned long long m_free = __ballot(leaving) | __ballot(slot == NO_SLOT);
+      const uint32_t n_free = (uint32_t)__popcll(m_free);
       unsigned long long mq = 0ull;  // the lanes handing in to the same queue as this one
       uint32_t cnt = 0;
 #pragma unroll
@@ -1112,27 +1147,28 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       if (lane < (uint32_t)N_QUEUES) {
         if (cnt) got = atomicAdd(&sh.queue_n[lane], cnt);
       } else if (lane == (uint32_t)N_QUEUES && more) {
-        got = atomicAdd(&sh.next_work, n_out);
+        got = atomicAdd(&sh.next_work, n_free);
       }
       const uint32_t base = __builtin_amdgcn_readlane(got, N_QUEUES);
       const uint32_t bq = __shfl(got, q < 0 ? 0 : q);  // every lane takes part: the reserving lanes may not be done
-      if (done) {
+      if (leaving) {
         const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
         // the whole path record moves into the queue, hit included: shading reads its queue front to back
         float4* const out = region_queues + 4 * ((size_t)q * cap + pos);
         out[0] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, w.r.time);
         out[1] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, pixel_bits);
         out[2] = state;
-        out[3] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), 0.0f);
+        out[3] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), __uint_as_float(saved_at));
         slot = NO_SLOT;
+        w.cur = RC::NONE;
         if (LDS_SCENE || q != QUEUE_CONTINUE) ++segments;
       }
       if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_WRITE] += now - ts; ts = now; }
       // (the lanes refilled together get consecutive slots: new camera paths of one pixel tile, which walk
       // the tree together)
       if (more) {
-        more = base + n_out < total;
-        const uint32_t entry = base + (uint32_t)__popcll(m_out & ((1ull << lane) - 1ull));
+        more = base + n_free < total;
+        const uint32_t entry = base + (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
         if (slot == NO_SLOT && entry < total) {
           slot = entry;
           const float4 r0 = cur[4 * (size_t)slot], r1 = cur[4 * (size_t)slot + 1];
@@ -1141,20 +1177,19 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
           walk_begin(w, r, root);
-          if (!LDS_SCENE && chunk_len > 0.0f) {
-            // This round's stretch: from where the last one ended, chunk_len further; if the ray has left the
-            // scene's bounds by then this is its last stretch.  (best_t stays at the stretch's end until a hit
-            // is found, which the tests accept up to and including that distance.)
-            w.t_lo = cur[4 * (size_t)slot + 3].x;
-            // (the second term keeps a stretch from rounding to nothing far along a ray)
-            const float d2 = len2(r.d);
-            const float t_hi = fmaxf(w.t_lo + chunk_len * __builtin_amdgcn_rsqf(d2), w.t_lo * 1.0009765625f);
-            float t_enter;
-            // how far the ray stays inside the (padded) bounds: slab() with the far end open reports entry <= exit
-            const bool inside = slab(root_lo, root_hi, r.o, w.inv, t_hi, kInf, t_enter);
-            // (a ray without a proper direction or origin is walked in one go: it has no stretch that ever ends)
-            const bool proper = d2 > 0.0f && d2 < kInf && fabsf(r.o.x) < kInf && fabsf(r.o.y) < kInf && fabsf(r.o.z) < kInf;
-            w.best_t = inside && proper && t_hi < kInf ? t_hi : kInf;
+          if (!LDS_SCENE && step_budget != 0u) {
+            const uint32_t saved_in = __float_as_uint(cur[4 * (size_t)slot + 3].x);
+            if (saved_in != 0u) {  // a walk put aside in the last round: on from where it stopped
+              const uint4* const sv = saves_in + (size_t)SAVE_QUADS * (saved_in - 1u);
+              const uint4 a = sv[0], b = sv[1];
+              w.cur = a.x; w.sp = a.y; w.best_ref = a.z; w.best_order = a.w;
+              w.best_t = __uint_as_float(b.x); w.best_material = b.y; w.best_face = b.z;
+              for (uint32_t k = 0; k < w.sp; k += 4u) {
+                const uint4 e = sv[2u + (k >> 2)];
+                stack[k * THREADS] = e.x; stack[(k + 1u) * THREADS] = e.y;
+                stack[(k + 2u) * THREADS] = e.z; stack[(k + 3u) * THREADS] = e.w;
+              }
+            }
           }
         }
       }
@@ -1163,14 +1198,16 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
     if (COUNT) ts = clock64();
     while (!(w.cur & RC::LEAF)) {
       if (COUNT) { ++work.nodes; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_nodes; }
-      node_step<LDS_SCENE>(w, tb, LDS_SCENE ? kTMin : w.t_lo, stack, THREADS);
+      node_step<LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+      if (!LDS_SCENE) ++w.steps;
       // the last few lanes still on their way down do not keep the others waiting
       if ((uint32_t)__popcll(__ballot(!(w.cur & RC::LEAF))) < node_min) break;
     }
     if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_NODES] += now - ts; ts = now; }
     if ((w.cur & RC::LEAF) && w.cur != RC::NONE) {
       if (COUNT) { ++work.prims; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_prims; }
-      prim_step<PSTRIDE, LDS_SCENE>(w, tb, LDS_SCENE ? kTMin : w.t_lo, stack, THREADS);
+      prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+      if (!LDS_SCENE) ++w.steps;
     }
     if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - ts;
   }
@@ -1295,7 +1332,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
          {A->rc.by_width.m, A->rc.by_width.sh1, A->rc.by_width.sh2}};
   const uint32_t cap = A->rc.region_cap;
   const uint32_t estimator = A->rc.estimator;
-  const bool chunked = !LDS_SCENE && A->chunk_len > 0.0f;
+  const bool budgeted = !LDS_SCENE && A->step_budget != 0u;
   float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
   float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   float* const rgb_sum = A->rgb_sum;
@@ -1331,7 +1368,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       Ray nr;
       V3 beta = v3(0.0f, 0.0f, 0.0f);
       uint32_t pixel = 0, sample = 0, bounce = 0;
-      float next_lo = kTMin;  // where the walk of the surviving ray starts looking
+      uint32_t saved_walk = 0;  // 1 + entry of the save area for a ray whose walk was put aside
       if (e < n_q) {
         const float4* const rec = entries + 4 * (size_t)e;
         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
@@ -1344,7 +1381,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         float t = r3.x;
         uint32_t ref = __float_as_uint(r3.y);
         bool deferred = false;
-        const bool goes_on = !LDS_SCENE && q == (uint32_t)QUEUE_CONTINUE;  // t: where its next stretch starts
+        const bool goes_on = !LDS_SCENE && q == (uint32_t)QUEUE_CONTINUE;  // its walk goes on in the next round
         if (n_media != 0 && pass == 0 && !goes_on) {  // the walk found the closest surface; the media in front of it get their chance now
           uint32_t material = 0;
           const uint32_t surface = ref;
@@ -1365,7 +1402,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         V3 term = v3(0.0f, 0.0f, 0.0f);  // radiance that ends the path
         if (goes_on) {  // back into the pool as it is
           nr = r;
-          next_lo = t;
+          saved_walk = __float_as_uint(r3.w);
           bounce -= 1u;  // (the survivor's record counts one bounce more than `bounce`)
           alive = true;
         } else if (deferred) {
@@ -1442,7 +1479,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         next[4 * to] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
         next[4 * to + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
         next[4 * to + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
-        if (chunked) next[4 * to + 3] = make_float4(next_lo, 0.0f, 0.0f, 0.0f);
+        if (budgeted) next[4 * to + 3] = make_float4(__uint_as_float(saved_walk), 0.0f, 0.0f, 0.0f);
       }
     }
     if (n_media == 0 || pass == 1u) break;
@@ -1630,6 +1667,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       sh.n_next = 0;
       sh.shade_next = 0;
       sh.late_next = 0;
+      sh.n_saved = 0;
     }
     __syncthreads();  // also: the staged scene is complete before the first walk
     const uint32_t n_fresh = sh.n_fresh;

@@ -61,6 +61,7 @@ struct mirt_context {
   // render workspace, grown on demand and kept between calls
   DeviceBuffer paths[2];
   DeviceBuffer queues;
+  DeviceBuffer saves;
   DeviceBuffer state;
   DeviceBuffer args;
   DeviceBuffer work;
@@ -719,6 +720,8 @@ struct Workspace {
   RenderState* state;
   WorkCounters* work;
   RenderArgs* args;
+  uint4* saves;       // walks put aside: 2 * N_REGIONS * save_cap entries of SAVE_QUADS quads
+  uint32_t save_cap;
 };
 
 // The fixed workspace, cut up: [control page: state, counters, arguments][paths a][paths b][queues].
@@ -734,6 +737,8 @@ Workspace carve_static_workspace(void* base) {
   w.paths[0] = reinterpret_cast<float4*>(p);
   w.paths[1] = reinterpret_cast<float4*>(p + (size_t)STATIC_POOL_PATHS * 64);
   w.queues = reinterpret_cast<float4*>(p + (size_t)STATIC_POOL_PATHS * 128);
+  w.saves = reinterpret_cast<uint4*>(p + (size_t)STATIC_POOL_PATHS * 64 * (2 + N_QUEUES));
+  w.save_cap = STATIC_SAVE_CAP;
   return w;
 }
 
@@ -763,8 +768,11 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
     MIRT_HIP(ctx, ctx->state.ensure(sizeof(RenderState)));
     MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
     MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
+    const uint32_t save_cap = std::max(64u, job.rc.region_cap / 4);
+    MIRT_HIP(ctx, ctx->saves.ensure((size_t)2 * N_REGIONS * save_cap * SAVE_QUADS * 16));
     ws = Workspace{{ctx->paths[0].as<float4>(), ctx->paths[1].as<float4>()}, ctx->queues.as<float4>(),
-                   ctx->state.as<RenderState>(), ctx->work.as<WorkCounters>(), ctx->args.as<RenderArgs>()};
+                   ctx->state.as<RenderState>(), ctx->work.as<WorkCounters>(), ctx->args.as<RenderArgs>(),
+                   ctx->saves.as<uint4>(), save_cap};
   }
   // (the workspace keeps the last call's contents: the counters must start at zero, the rest is written before read)
   MIRT_HIP(ctx, hipMemsetAsync(ws.state, 0, sizeof(RenderState), stream));
@@ -800,18 +808,18 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.work = ws.work;
   args.rgb_sum = job.rgb_sum;
   args.refill_min = cfg.refill_min;
-  args.chunk_len = 0.0f;
-  // Large scenes (from 2^18 primitives): rays are walked a thirty-second of the bounds' diagonal per round.  The few
-  // rays that graze such a scene for thousands of steps then no longer hold up every round (1 M spheres: +57 %,
-  // 10 M: +95 %); smaller scenes have no such rays and only pay for the extra rounds (6.5 k spheres: -18 %).
-  if (!cfg.lds_scene && !job.rays && (scene->n_prims >= (1u << 18) || std::getenv("MIRT_CHUNKS"))) {
-    long chunks = 32;
-    if (const char* e = std::getenv("MIRT_CHUNKS")) chunks = std::strtol(e, nullptr, 10);  // tuning aid; 0 = whole rays
-    const DeviceScene& sv = scene->view;
-    const double dx = (double)sv.root_hi[0] - sv.root_lo[0], dy = (double)sv.root_hi[1] - sv.root_lo[1],
-                 dz = (double)sv.root_hi[2] - sv.root_lo[2];
-    const double diagonal = std::sqrt(dx * dx + dy * dy + dz * dz);
-    if (chunks > 0 && diagonal > 0.0 && std::isfinite(diagonal)) args.chunk_len = (float)(diagonal / (double)chunks);
+  // Large scenes (from 2^18 primitives): a ray takes at most `budget` steps per round; longer walks are put aside
+  // and go on in the next round, so the few rays that graze such a scene for thousands of steps no longer hold up
+  // every round.  Smaller scenes have no such rays and would only pay for the bookkeeping.
+  args.step_budget = 0;
+  args.save_cap = ws.save_cap;
+  args.saves = ws.saves;
+  if (!cfg.lds_scene && !job.rays && (scene->n_prims >= (1u << 18) || std::getenv("MIRT_STEP_BUDGET"))) {
+    // (1 M spheres: 256 steps is best, +22 % over walking a thirty-second of the scene's diagonal per round and +85 %
+    // over whole rays; 10 M: 1024, +21 % and +144 % -- deeper trees, longer walks, dearer rounds)
+    long budget = scene->n_prims >= (1u << 22) ? 1024 : 256;
+    if (const char* e = std::getenv("MIRT_STEP_BUDGET")) budget = std::strtol(e, nullptr, 10);  // tuning aid; 0 = whole rays
+    if (budget > 0) args.step_budget = (uint32_t)std::min<long>(budget, 1 << 30);
   }
   args.node_min = cfg.node_min;
   args.rays = job.rays;

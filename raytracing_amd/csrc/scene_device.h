@@ -161,7 +161,7 @@ struct WorkCounters {
 // single-colour Lambertian hits are split once more by the primitive hit (spheres and media / rects and boxes: the
 // hit records are worked out by different code, and the survivors of one queue start near each other, which keeps
 // the next walk's waves on the same kind of primitive).  The material word names queues 0..4.
-// QUEUE_CONTINUE holds rays of a large scene that found nothing in the stretch walked this round: they go back
+// QUEUE_CONTINUE holds rays of a large scene whose walk used up its step budget this round: they go back
 // into the pool unshaded and walk their next stretch in the next round.  QUEUE_MISS: rays that hit nothing (only
 // the media and the background are left for them; apart from the surfaces that end a path in QUEUE_TERMINATE).
 constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3,
@@ -209,6 +209,9 @@ struct RenderConst {
 //        into a shading queue; the two record buffers carry r0..r2)
 // Shading queue q of region s holds whole path records (the walk moves a finished ray's record there, hit
 // included) at queues[4 * (s * N_QUEUES + q) * region_cap ...]: shading reads a queue front to back.
+// A walk put aside: (reference in hand, stack entries in use, best ref, best order), (best t, best material word,
+// best box side, -), then the STACK_DEPTH stack entries, four to a quad.
+constexpr uint32_t SAVE_QUADS = 2 + STACK_DEPTH / 4;
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
 constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
@@ -217,8 +220,11 @@ constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 // holding a path pool of STATIC_POOL_PATHS records (two record buffers and N_QUEUES queues: 640 bytes a path)
 // behind a control page with the render's counters and launch arguments.
 constexpr uint32_t STATIC_POOL_PATHS = 65536;
+constexpr uint32_t STATIC_SAVE_CAP = 32;  // walks put aside per region and round in the fixed workspace
 constexpr size_t STATIC_CONTROL_BYTES = 4096;
-constexpr size_t STATIC_WORKSPACE_BYTES = STATIC_CONTROL_BYTES + (size_t)STATIC_POOL_PATHS * 64 * (2 + N_QUEUES);
+constexpr size_t STATIC_SAVE_BYTES = (size_t)N_REGIONS * 2 * STATIC_SAVE_CAP * 16 * (2 + STACK_DEPTH / 4);
+constexpr size_t STATIC_WORKSPACE_BYTES =
+    STATIC_CONTROL_BYTES + (size_t)STATIC_POOL_PATHS * 64 * (2 + N_QUEUES) + STATIC_SAVE_BYTES;
 // Address of the current device's copy (`device` must be the current device); looked up once per device.
 hipError_t static_workspace_address(int device, void** out);
 
@@ -247,9 +253,13 @@ struct RenderArgs {
   WorkCounters* work;
   float* rgb_sum;
   uint32_t refill_min, node_min;
-  // Scenes walked from global memory: a ray is walked this far (world distance) per round, so that the few rays
-  // that graze a large scene for thousands of steps do not hold up the round for everyone; 0 = to the end.
-  float chunk_len;
+  // Scenes walked from global memory: a ray takes at most this many steps (tree steps + primitive tests) per
+  // round; then its walk is put aside in `saves` (save_cap entries of SAVE_QUADS quads per region and round
+  // parity) and goes on in the next round, so that the few rays that graze a large scene for thousands of steps do
+  // not hold up the round for everyone; 0 = every ray is walked to the end.
+  uint32_t step_budget;
+  uint32_t save_cap;
+  uint4* saves;
   // Tracing caller-supplied rays instead of rendering (rays != nullptr): rc.total_paths rays come from `rays`,
   // each is walked once, and what ray g hit goes to hit_type[g], hit_object[g], hit_t[g] (and hit_records).
   const mirt_ray* rays;

@@ -238,37 +238,41 @@ def test_device_built_tree_finds_the_same_hits(name, lo, hi, monkeypatch):
         o.close()
 
 
-@pytest.mark.parametrize("chunks", ["7", "64", "1000"])
-def test_rays_walked_in_stretches_find_the_same_hits(chunks, monkeypatch):
-    """Large scenes walk a ray a stretch of the scene's diagonal per round and carry it over if nothing was hit
-    (forced here on the 6.5 k-sphere scene): the closest hit is the first stretch with a hit, so the image is the one
-    whole-ray walks give, and the oracle's."""
+@pytest.mark.parametrize("budget", ["3", "40", "1000"])
+def test_walks_put_aside_and_resumed_find_the_same_hits(budget, monkeypatch):
+    """Large scenes give a ray a budget of steps per round; a walk that uses it up is put aside (place in the tree,
+    stack, closest hit so far) and goes on in the next round (forced here on the 6.5 k-sphere scene, with budgets
+    from "nearly every ray, many times" to "hardly any").  The steps are the same steps in the same order, so
+    the image is the one whole-ray walks give, and the oracle's."""
     name, w, h, spp = "synthetic_bvh:40", 96, 54, 4
     g, o = R.ExampleScene(name), O.Scene(name)
     try:
-        monkeypatch.setenv("MIRT_CHUNKS", "0")
+        monkeypatch.setenv("MIRT_STEP_BUDGET", "0")
         whole, whole_sums, st0 = g.render(w, h, spp, seed=21, flags=R.MIRT_RENDER_COUNT_WORK)
-        monkeypatch.setenv("MIRT_CHUNKS", chunks)
+        monkeypatch.setenv("MIRT_STEP_BUDGET", budget)
         rgb, sums, st = g.render(w, h, spp, seed=21, flags=R.MIRT_RENDER_COUNT_WORK)
         orgb, osums, oseg = o.render(w, h, spp, seed=21)
     finally:
         g.close()
         o.close()
     assert st["segments"] == st0["segments"]
-    assert st["iterations"] > st0["iterations"]          # more rounds: rays were carried over
+    # not one step more or less than whole-ray walks take
+    assert st["nodes_visited"] == st0["nodes_visited"] and st["prims_tested"] == st0["prims_tested"]
+    if budget != "1000":
+        assert st["iterations"] > st0["iterations"]          # more rounds: rays were carried over
     ok = np.isfinite(sums) & np.isfinite(whole_sums)
     assert np.array_equal(np.isfinite(sums), np.isfinite(whole_sums))
-    assert np.allclose(sums[ok], whole_sums[ok], rtol=1e-4, atol=1e-5)
+    assert np.allclose(sums[ok], whole_sums[ok], rtol=1e-5, atol=1e-6)
     assert float(O.psnr(rgb, orgb)) > 55.0
     assert abs(st["segments"] - oseg) <= max(8, oseg // 20000)
 
 
 def test_large_scene_library_defaults(scenes):
     """A scene of more than 2^18 primitives with nothing overridden: the library picks the device (Morton order)
-    builder and walks camera paths in stretches.  Closest-hit ids and t bits of caller rays against the oracle's
+    builder and gives camera paths a step budget per round.  Closest-hit ids and t bits of caller rays against the oracle's
     bvh.rs tournament, then a same-seed render whose round count shows rays were carried from round to round."""
     import os
-    for var in ("MIRT_BVH_BUILDER", "MIRT_CHUNKS", "MIRT_LEAF_MAX", "MIRT_REFILL_MIN", "MIRT_NODE_MIN"):
+    for var in ("MIRT_BVH_BUILDER", "MIRT_STEP_BUDGET", "MIRT_LEAF_MAX", "MIRT_REFILL_MIN", "MIRT_NODE_MIN"):
         assert var not in os.environ
     g, o = scenes("synthetic_bvh:256")                      # 513 x 513 cells
     n = g.primitive_count()
@@ -279,10 +283,11 @@ def test_large_scene_library_defaults(scenes):
                            random_rays(500, [-400, 0.01, -400], [400, 60, 400], 32)])     # above and around it
     assert_same_hits(g, o, rays)
     depth = 6
-    rgb, sums, st = g.render(32, 18, 1, depth=depth, seed=21)
-    assert not st["scene_in_lds"]
     # every path of this frame is in flight at once, so whole-ray walks would take one round per bounce
+    _, _, st = g.render(480, 270, 1, depth=depth, seed=21)
+    assert not st["scene_in_lds"]
     assert st["iterations"] > depth, "no ray was carried over to another round"
+    rgb, sums, st = g.render(32, 18, 1, depth=depth, seed=21)
     orgb, osums, _ = o.render(32, 18, 1, depth=depth, seed=21)
     ok = np.isfinite(osums).all(axis=2)
     close = np.isclose(sums, osums, rtol=1e-4, atol=1e-5).all(axis=2)
