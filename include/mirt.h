@@ -396,6 +396,29 @@ int mirt_render_accumulate_static(mirt_context* ctx, const mirt_scene* scene, co
                                   mirt_stats* stats);
 int mirt_static_workspace_paths(void);
 
+/* ---- a frame that is rendered in passes, shown while it converges, stopped and continued ---------------------
+ * The reference renders a frame in one go and shows it when it is done (renderer.rs:43-138).  A mirt_frame keeps
+ * the f32 sums of a frame on the device (the first device of a context over several) together with the number of
+ * samples in them; every mirt_frame_render adds params->samples_per_pixel more samples per pixel, numbered on from
+ * the frame's count (params->first_sample is ignored), so that any sequence of passes, with any number of saves and
+ * loads in between, ends up as the image of one uninterrupted render, up to the order of the f32 sums.  Width,
+ * height, seed, max_depth and the estimator flags are fixed by the first pass (or by the checkpoint) and later
+ * passes that disagree are rejected. */
+typedef struct mirt_frame mirt_frame;
+int mirt_frame_create(mirt_context* ctx, uint32_t width, uint32_t height, mirt_frame** out);
+void mirt_frame_destroy(mirt_context* ctx, mirt_frame* frame);
+int mirt_frame_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
+                      const mirt_render_params* params, mirt_frame* frame, mirt_stats* stats);
+/* samples per pixel in the frame so far */
+uint32_t mirt_frame_samples(const mirt_frame* frame);
+/* The frame as it stands, encoded as renderer.rs:232-259 for the samples it holds: what Renderer::present
+ * (renderer.rs:94-138) would show.  Either output may be NULL; both are host arrays of width*height*3. */
+int mirt_frame_read(mirt_context* ctx, const mirt_frame* frame, uint8_t* rgb24_out, float* rgb_sum_out);
+/* Checkpoint: "MIRTACC1", u32 header length, a JSON header (width, height, samples, seed, depth, flags), then the
+ * f32 sums, little endian, row 0 = image top.  mirt_frame_load makes a new frame from such a file. */
+int mirt_frame_save(mirt_context* ctx, const mirt_frame* frame, const char* path);
+int mirt_frame_load(mirt_context* ctx, const char* path, mirt_frame** out);
+
 /* renderer.rs:232-259 on the device: sums of `samples_per_pixel` samples ->
  * RGB24.  Both pointers are device pointers. */
 int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width, uint32_t height,

@@ -163,7 +163,8 @@ class Ray(C.Structure):
 
 MIRT_SYMBOLS = ["mirt_context_create", "mirt_context_create_multi", "mirt_context_device_count", "mirt_context_destroy", "mirt_last_error", "mirt_scene_upload",
                 "mirt_scene_destroy", "mirt_render", "mirt_render_accumulate", "mirt_render_accumulate_static",
-                "mirt_static_workspace_paths", "mirt_resolve",
+                "mirt_static_workspace_paths", "mirt_resolve", "mirt_frame_create", "mirt_frame_destroy",
+                "mirt_frame_render", "mirt_frame_samples", "mirt_frame_read", "mirt_frame_save", "mirt_frame_load",
                 "mirt_trace_primary", "mirt_trace_records", "mirt_trace_device", "mirt_version"]
 
 
@@ -210,6 +211,19 @@ def mirt():
     L.mirt_resolve.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.mirt_trace_primary.restype = C.c_int
     L.mirt_trace_primary.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, vp, vp, vp]
+    L.mirt_frame_create.restype = C.c_int
+    L.mirt_frame_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.mirt_frame_destroy.argtypes = [vp, vp]
+    L.mirt_frame_render.restype = C.c_int
+    L.mirt_frame_render.argtypes = [vp, vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, C.POINTER(Stats)]
+    L.mirt_frame_samples.restype = C.c_uint32
+    L.mirt_frame_samples.argtypes = [vp]
+    L.mirt_frame_read.restype = C.c_int
+    L.mirt_frame_read.argtypes = [vp, vp, vp, vp]
+    L.mirt_frame_save.restype = C.c_int
+    L.mirt_frame_save.argtypes = [vp, vp, C.c_char_p]
+    L.mirt_frame_load.restype = C.c_int
+    L.mirt_frame_load.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.mirt_trace_records.restype = C.c_int
     L.mirt_trace_records.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, vp]
     L.mirt_trace_device.restype = C.c_int

@@ -1103,6 +1103,182 @@ int mirt_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   return MIRT_OK;
 }
 
+}  // extern "C"
+
+struct mirt_frame {
+  DeviceBuffer sums;
+  uint32_t width = 0, height = 0;
+  uint32_t samples = 0;
+  bool started = false;  // seed, depth and flags are fixed from the first pass on
+  uint64_t seed = 0;
+  uint32_t max_depth = 0, flags = 0;
+  size_t values() const { return (size_t)width * height * 3; }
+};
+
+extern "C" {
+
+int mirt_frame_create(mirt_context* ctx, uint32_t width, uint32_t height, mirt_frame** out) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (width < 2 || height < 2 || (uint64_t)width * height >= (1ull << 30))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "bad frame size");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  mirt_frame* f = new (std::nothrow) mirt_frame();
+  if (!f) return fail(ctx, MIRT_ERR_OUT_OF_MEMORY, "out of host memory");
+  f->width = width;
+  f->height = height;
+  hipError_t e = f->sums.ensure(f->values() * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(f->sums.ptr, 0, f->values() * sizeof(float));
+  if (e != hipSuccess) {
+    delete f;
+    return fail(ctx, e == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_DEVICE, hipGetErrorString(e));
+  }
+  *out = f;
+  return MIRT_OK;
+}
+
+void mirt_frame_destroy(mirt_context* ctx, mirt_frame* frame) {
+  if (ctx) (void)hipSetDevice(ctx->device);
+  delete frame;
+}
+
+uint32_t mirt_frame_samples(const mirt_frame* frame) { return frame ? frame->samples : 0; }
+
+int mirt_frame_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
+                      const mirt_render_params* params, mirt_frame* frame, mirt_stats* stats) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!scene || !camera || !params || !frame) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  if (params->width != frame->width || params->height != frame->height)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "the pass is not of the frame's size");
+  if (params->n_rows != 0 && (params->first_row != 0 || params->n_rows != params->height))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "a frame is rendered whole: no row window");
+  const uint32_t estimator = params->flags & (MIRT_RENDER_EVEN_LIGHTS | MIRT_RENDER_DROP_NONFINITE | MIRT_RENDER_STRATA_MASK);
+  if (frame->started && (params->seed != frame->seed || params->max_depth != frame->max_depth || estimator != frame->flags))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "seed, max_depth or estimator flags differ from the frame's earlier passes");
+  if ((uint64_t)frame->samples + params->samples_per_pixel - 1 > MAX_SAMPLE_INDEX)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "sample index beyond 2^24 - 1");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  mirt_render_params p = *params;
+  p.first_sample = frame->samples;
+  p.first_row = 0;
+  p.n_rows = 0;
+  int rc;
+  if (ctx->others.empty()) {
+    // straight into the frame's sums
+    rc = render_impl(ctx, scene, camera, &p, frame->sums.as<float>(), ctx->stream, stats);
+  } else {
+    // the devices' shares are gathered in the context's own image, which is then added to the frame
+    MIRT_HIP(ctx, ctx->image_sum.ensure(frame->values() * sizeof(float)));
+    MIRT_HIP(ctx, hipMemsetAsync(ctx->image_sum.ptr, 0, frame->values() * sizeof(float), ctx->stream));
+    rc = render_shared(ctx, scene, camera, &p, stats);
+    if (rc == MIRT_OK) {
+      launch_add(frame->sums.as<float>(), ctx->image_sum.as<float>(), frame->values(), ctx->stream);
+      MIRT_HIP(ctx, hipGetLastError());
+      MIRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  if (rc != MIRT_OK) return rc;
+  frame->started = true;
+  frame->seed = params->seed;
+  frame->max_depth = params->max_depth;
+  frame->flags = estimator;
+  frame->samples += params->samples_per_pixel;
+  return MIRT_OK;
+}
+
+int mirt_frame_read(mirt_context* ctx, const mirt_frame* frame, uint8_t* rgb24_out, float* rgb_sum_out) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!frame) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = frame->values();
+  if (rgb24_out) {
+    if (frame->samples == 0) {
+      std::memset(rgb24_out, 0, n);
+    } else {
+      MIRT_HIP(ctx, ctx->image_rgb.ensure(n));
+      launch_resolve(frame->sums.as<float>(), (uint32_t)n, frame->samples, ctx->image_rgb.as<uint8_t>(), ctx->stream);
+      MIRT_HIP(ctx, hipGetLastError());
+      MIRT_HIP(ctx, hipMemcpyAsync(rgb24_out, ctx->image_rgb.ptr, n, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  if (rgb_sum_out)
+    MIRT_HIP(ctx, hipMemcpyAsync(rgb_sum_out, frame->sums.ptr, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  MIRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MIRT_OK;
+}
+
+int mirt_frame_save(mirt_context* ctx, const mirt_frame* frame, const char* path) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!frame || !path) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<float> host(frame->values());
+  const int rc = mirt_frame_read(ctx, frame, nullptr, host.data());
+  if (rc != MIRT_OK) return rc;
+  char head[256];
+  const int len = std::snprintf(head, sizeof(head),
+                                "{\"width\": %u, \"height\": %u, \"samples\": %u, \"seed\": %llu, \"depth\": %u, "
+                                "\"flags\": %u, \"started\": %u}",
+                                frame->width, frame->height, frame->samples, (unsigned long long)frame->seed,
+                                frame->max_depth, frame->flags, frame->started ? 1u : 0u);
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string("cannot write ") + path);
+  const uint32_t len32 = (uint32_t)len;  // (the file is little endian, as is every host this library runs on)
+  bool ok = std::fwrite("MIRTACC1", 1, 8, f) == 8 && std::fwrite(&len32, 4, 1, f) == 1 &&
+            std::fwrite(head, 1, (size_t)len, f) == (size_t)len &&
+            std::fwrite(host.data(), sizeof(float), host.size(), f) == host.size();
+  ok = (std::fclose(f) == 0) && ok;
+  return ok ? MIRT_OK : fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string("short write on ") + path);
+}
+
+int mirt_frame_load(mirt_context* ctx, const char* path, mirt_frame** out) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  if (!path || !out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string("cannot read ") + path);
+  struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+  char magic[8];
+  uint32_t len = 0;
+  if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, "MIRTACC1", 8) != 0 || std::fread(&len, 4, 1, f) != 1 || len >= 4096)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string(path) + ": not a checkpoint of this library");
+  std::string head(len, '\0');
+  if (std::fread(&head[0], 1, len, f) != len) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string(path) + ": truncated checkpoint");
+  // the header's numbers, by key (keys this version does not know are skipped; absent ones read as 0)
+  auto number = [&](const char* key, bool& found) -> unsigned long long {
+    const std::string k = std::string("\"") + key + "\":";
+    const size_t at = head.find(k);
+    found = at != std::string::npos;
+    return found ? std::strtoull(head.c_str() + at + k.size(), nullptr, 10) : 0ull;
+  };
+  bool has_w, has_h, has_s, has_seed, has_depth, has_flags, has_started;
+  const unsigned long long w = number("width", has_w), h = number("height", has_h), n = number("samples", has_s),
+                           seed = number("seed", has_seed), depth = number("depth", has_depth),
+                           flags = number("flags", has_flags), started = number("started", has_started);
+  if (!has_w || !has_h || !has_s || !has_seed || !has_depth || n > MAX_SAMPLE_INDEX + 1ull || w > 0xFFFFFFFFull || h > 0xFFFFFFFFull)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string(path) + ": checkpoint header incomplete");
+  mirt_frame* frame = nullptr;
+  const int rc = mirt_frame_create(ctx, (uint32_t)w, (uint32_t)h, &frame);
+  if (rc != MIRT_OK) return rc;
+  std::vector<float> host(frame->values());
+  char extra;
+  if (std::fread(host.data(), sizeof(float), host.size(), f) != host.size() || std::fread(&extra, 1, 1, f) != 0) {
+    mirt_frame_destroy(ctx, frame);
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string(path) + ": truncated checkpoint");
+  }
+  const hipError_t e = hipMemcpy(frame->sums.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    mirt_frame_destroy(ctx, frame);
+    return fail(ctx, MIRT_ERR_DEVICE, hipGetErrorString(e));
+  }
+  frame->samples = (uint32_t)n;
+  frame->seed = seed;
+  frame->max_depth = (uint32_t)depth;
+  frame->flags = (uint32_t)flags;
+  frame->started = has_started ? started != 0 : n != 0;
+  *out = frame;
+  return MIRT_OK;
+}
+
 static int trace_device_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays_device, size_t n,
                              uint64_t seed, uint32_t* type_index_device, uint32_t* object_index_device,
                              float* t_device, float4* records_device, void* stream) {

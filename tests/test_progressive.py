@@ -4,7 +4,7 @@ import pytest
 
 import oracle_lib as O
 import raytracing_amd as R
-from raytracing_amd.progressive import Progressive, encode_rgb24
+from raytracing_amd.progressive import Frame, Progressive, encode_rgb24
 
 
 def test_host_encoder_matches_the_oracle_encoder():
@@ -56,3 +56,50 @@ def test_resumed_render_equals_uninterrupted_one(tmp_path):
     assert np.allclose(second.sums[ok], straight.sums[ok], rtol=1e-4, atol=1e-5)
     diff = np.abs(second.image().astype(int) - straight.image().astype(int))
     assert diff[ok].max() <= 1
+
+
+@pytest.mark.gpu
+def test_device_frame_passes_checkpoint_and_resume_against_the_oracle(tmp_path):
+    """mirt_frame_*: sums stay on the GPU, passes add on the device, the library writes and reads the checkpoint.
+    10 samples in passes of 4, save, load, 14 more: the sums are the oracle's same-seed 24-sample sums (a libm
+    rounding may flip a path), the uninterrupted GPU render's to f32 summation order, and the preview is the
+    reference's encoding of the samples so far."""
+    g, o = R.ExampleScene("cornel_box"), O.Scene("cornel_box")
+    w, h = 96, 96
+    fr = Frame(g, w, h, seed=5, aspect=1.0)
+    assert fr.samples == 0 and not fr.read()[0].any()
+    fr.render(10, pass_size=4)
+    assert fr.samples == 10
+    rgb10, sums10 = fr.read()
+    _, osums10, _ = o.render(w, h, 10, aspect=1.0, seed=5)
+    ok = np.isfinite(osums10).all(axis=2) & np.isfinite(sums10).all(axis=2)
+    assert np.mean(np.isclose(sums10, osums10, rtol=1e-4, atol=1e-5).all(axis=2)[ok]) > 0.98
+    assert np.array_equal(rgb10, O.encode(sums10, 10))                # the preview: renderer.rs:232-259 for 10 samples
+    fr.save(tmp_path / "f.ckpt")
+    fr.close()
+    # the host-side reader understands the library's file
+    host = Progressive.load(g, tmp_path / "f.ckpt")
+    assert host.samples == 10 and np.array_equal(host.sums.view(np.uint32), sums10.view(np.uint32))
+    back = Frame.load(g, tmp_path / "f.ckpt", aspect=1.0)
+    assert back.samples == 10 and (back.width, back.height, back.seed, back.depth) == (w, h, 5, g.depth)
+    assert np.array_equal(back.read()[1].view(np.uint32), sums10.view(np.uint32))
+    back.render(14, pass_size=5)
+    assert back.samples == 24
+    rgb, sums = back.read()
+    _, osums, _ = o.render(w, h, 24, aspect=1.0, seed=5)
+    ok = np.isfinite(osums).all(axis=2) & np.isfinite(sums).all(axis=2)
+    assert ok.mean() > 0.99
+    assert np.mean(np.isclose(sums, osums, rtol=1e-4, atol=1e-5).all(axis=2)[ok]) > 0.97
+    straight = g.render(w, h, 24, aspect=1.0, seed=5)[1]
+    both = ok & np.isfinite(straight).all(axis=2)
+    assert np.allclose(sums[both], straight[both], rtol=1e-5, atol=1e-6)
+    # a pass that disagrees with the frame's earlier ones is rejected, and so is a damaged file
+    back.seed = 6
+    with pytest.raises(R.MirtError, match="differ"):
+        back.render(1)
+    back.close()
+    p = tmp_path / "f.ckpt"
+    p.write_bytes(p.read_bytes()[:-4])
+    with pytest.raises(R.MirtError, match="truncated"):
+        Frame.load(g, p)
+    g.close()
