@@ -184,4 +184,39 @@ BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t 
   return out;
 }
 
+namespace {
+
+struct Refit {
+  std::vector<HostNode>& nodes;
+  const std::vector<BuildPrim>& prims;
+  // box of everything under `ref`; a missing child has the empty box
+  Box fit(uint32_t ref) {
+    Box b;
+    b.reset();
+    if (ref == 0xFFFFFFFFu) return b;
+    if (ref & 0x80000000u) {
+      const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
+      for (uint32_t k = first; k < first + count && k < prims.size(); ++k) b.grow(prims[k].mn, prims[k].mx);
+      return b;
+    }
+    const uint32_t left = nodes[ref].left, right = nodes[ref].right;
+    const Box l = fit(left), r = fit(right);
+    HostNode& nd = nodes[ref];
+    for (int a = 0; a < 3; ++a) {
+      if (left != 0xFFFFFFFFu) { nd.lmin[a] = l.mn[a]; nd.lmax[a] = l.mx[a]; }
+      if (right != 0xFFFFFFFFu) { nd.rmin[a] = r.mn[a]; nd.rmax[a] = r.mx[a]; }
+    }
+    b = l;
+    b.grow(r.mn, r.mx);
+    return b;
+  }
+};
+
+}  // namespace
+
+void refit_bvh(std::vector<HostNode>& nodes, uint32_t root_ref, const std::vector<BuildPrim>& prims) {
+  Refit r{nodes, prims};
+  (void)r.fit(root_ref);
+}
+
 }  // namespace mirt

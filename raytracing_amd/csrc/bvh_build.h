@@ -43,4 +43,8 @@ struct BuiltBvh {
 // (a smaller tree).
 BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t leaf_max, float step_cost = 1.0f);
 
+// Recomputes every child box of a built tree (same nodes, same leaves) from other primitive boxes: `prims` in tree
+// order, as the build left them.  Used to fit one tree to the primitives' positions in several slices of time.
+void refit_bvh(std::vector<HostNode>& nodes, uint32_t root_ref, const std::vector<BuildPrim>& prims);
+
 }  // namespace mirt

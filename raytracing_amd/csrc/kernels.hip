@@ -336,10 +336,22 @@ struct Walk {
   float best_t;
   uint32_t best_ref, best_order, best_material, best_face, cur, sp;
   uint32_t steps;  // tree steps and primitive tests this ray has taken in the current round
+  uint32_t node_base;  // first quad of the copy of the node array fitted to the ray's time
 };
 
-__device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root) {
+// The copy of the node array a ray of time `time` walks, as an offset in quads.
+__device__ __forceinline__ uint32_t time_slice_base(float time, uint32_t n_slices, float time0, float scale,
+                                                    uint32_t n_nodes) {
+  if (n_slices <= 1u) return 0u;
+  const float f = (time - time0) * scale;
+  uint32_t s = f > 0.0f ? (uint32_t)f : 0u;  // (NaN: slice 0; ray times are checked against the scene's range)
+  if (s >= n_slices) s = n_slices - 1u;
+  return s * n_nodes * 4u;
+}
+
+__device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root, uint32_t node_base) {
   w.r = r;
+  w.node_base = node_base;
   // the reciprocals only steer the conservative box test: the hardware approximation lies well inside its padding
   w.inv = v3(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
   w.best_t = kInf;
@@ -358,7 +370,7 @@ __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root)
 template <bool COMPACT, class Slot>
 __device__ __forceinline__ void node_step(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride) {
   using RC = RefCode<COMPACT>;
-  const float4* n = tb.nodes + 4 * (size_t)w.cur;
+  const float4* n = tb.nodes + (w.node_base + 4 * (size_t)w.cur);
   const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
   float tl, tr;
   const bool hl = slab(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, tl);
@@ -938,7 +950,7 @@ struct RenderLds {
   __device__ __forceinline__ RenderLds(float4* smem, ConstArgs A) {
     float4* after = smem + SHARED_BYTES / 16;
     nodes = after;
-    prims = nodes + (LDS_SCENE ? A->sc.n_nodes * 4u : 0u);
+    prims = nodes + (LDS_SCENE ? A->sc.n_nodes * A->sc.n_slices * 4u : 0u);
     ops = prims + (LDS_SCENE ? A->sc.n_prims * PRIM_QUADS_LDS : 0u);
     chains = ops + (LDS_SCENE ? A->sc.n_chain_ops : 0u);
     materials = chains + (LDS_SCENE ? A->sc.n_chains * 2u : 0u);
@@ -1070,6 +1082,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   // queue q of the region: 64-byte records at [q * cap, (q + 1) * cap)
   float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   const uint32_t root = RC::encode(A->sc.root_ref);
+  const uint32_t n_slices = A->sc.n_slices, n_nodes = A->sc.n_nodes;
+  const float slice_time0 = A->sc.slice_time0, slice_scale = A->sc.slice_scale;
   const uint32_t refill_min = A->refill_min, node_min = A->node_min;
   // Scenes walked from global memory: a ray that has taken step_budget steps in this round is put aside -- its
   // place in the tree (reference in hand, stack, closest hit so far) goes into the region's save area, the ray
@@ -1176,7 +1190,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
           pixel_bits = r1.w;
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
-          walk_begin(w, r, root);
+          walk_begin(w, r, root, time_slice_base(r.time, n_slices, slice_time0, slice_scale, n_nodes));
           if (!LDS_SCENE && step_budget != 0u) {
             const uint32_t saved_in = __float_as_uint(cur[4 * (size_t)slot + 3].x);
             if (saved_in != 0u) {  // a walk put aside in the last round: on from where it stopped
@@ -1613,7 +1627,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       const RenderLds<true> lds(smem, A);
       const float4 *nodes = A->sc.nodes, *prims = A->sc.prims, *chain_ops = A->sc.chain_ops;
       const float4* chains = A->sc.chains;
-      const uint32_t n_node_quads = A->sc.n_nodes * 4u, n_prim_quads = A->sc.n_prims * PRIM_QUADS_LDS;
+      const uint32_t n_node_quads = A->sc.n_nodes * A->sc.n_slices * 4u, n_prim_quads = A->sc.n_prims * PRIM_QUADS_LDS;
       const uint32_t n_chain_ops = A->sc.n_chain_ops, n_chains = A->sc.n_chains;
       for (uint32_t k = threadIdx.x; k < n_node_quads; k += THREADS) {
         float4 q = nodes[k];
@@ -1792,7 +1806,7 @@ RenderConfig plan_render(const DeviceScene& sc) {
   // a stack entry per inner node on the path plus the pending sibling of the last one
   const int depth = (int)sc.bvh_height + 2;
   // nodes, 48-byte primitive records, wrapper chains; then what shading looks up: materials, textures, lights
-  const size_t scene_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_prims * PRIM_QUADS_LDS * 16 +
+  const size_t scene_bytes = (size_t)sc.n_nodes * std::max(1u, sc.n_slices) * 64 + (size_t)sc.n_prims * PRIM_QUADS_LDS * 16 +
                              (size_t)sc.n_chain_ops * 16 + (size_t)sc.n_chains * 32 +
                              (size_t)sc.n_materials * sizeof(DMaterial) + (size_t)sc.n_textures * sizeof(DTexture) +
                              (size_t)sc.n_lights * sizeof(DLight) + ((size_t)sc.n_light_groups + 1) / 2 * 16;

@@ -100,8 +100,12 @@ struct DeviceScene {
   uint32_t root_ref;
   uint32_t n_chains;  // 1 = only the empty chain: skip chain lookups entirely
 
-  uint32_t n_nodes;
+  uint32_t n_nodes;     // nodes of one copy of the tree
   uint32_t bvh_height;  // inner nodes on the longest root-to-leaf path
+  // Scenes with moving spheres keep n_slices copies of the node array, copy s fitted to where the spheres are
+  // during slice s of [slice_time0, slice_time0 + n_slices / slice_scale]: a ray walks the copy of its time.
+  uint32_t n_slices;
+  float slice_time0, slice_scale;
 
   const float4* prims;  // primitive records, layout above
   const uint2* prim_ids;
@@ -160,13 +164,14 @@ struct WorkCounters {
 // metal, glass, what ends the path (lights, Isotropic, misses), Lambertian surfaces with a texture to evaluate;
 // single-colour Lambertian hits are split once more by the primitive hit (spheres and media / rects and boxes: the
 // hit records are worked out by different code, and the survivors of one queue start near each other, which keeps
-// the next walk's waves on the same kind of primitive).  The material word names queues 0..4.
+// the next walk's waves on the same kind of primitive).  The material word names one of the material queues.
 // QUEUE_CONTINUE holds rays of a large scene whose walk used up its step budget this round: they go back
 // into the pool unshaded and walk their next stretch in the next round.  QUEUE_MISS: rays that hit nothing (only
 // the media and the background are left for them; apart from the surfaces that end a path in QUEUE_TERMINATE).
-constexpr int QUEUE_LAMBERTIAN = 0, QUEUE_METAL = 1, QUEUE_DIELECTRIC = 2, QUEUE_TERMINATE = 3,
-              QUEUE_LAMBERTIAN_TEXTURED = 4, QUEUE_LAMBERTIAN_FLAT = 5, QUEUE_CONTINUE = 6, QUEUE_MISS = 7,
-              N_QUEUES = 8;
+// QUEUE_CONTINUE comes first: its rays move into the first slots of the next round's buffer, so the next walk starts
+// with them -- the rays with the longest walks still ahead of them -- and the short ones fill the round's end.
+constexpr int QUEUE_CONTINUE = 0, QUEUE_LAMBERTIAN = 1, QUEUE_METAL = 2, QUEUE_DIELECTRIC = 3, QUEUE_TERMINATE = 4,
+              QUEUE_LAMBERTIAN_TEXTURED = 5, QUEUE_LAMBERTIAN_FLAT = 6, QUEUE_MISS = 7, N_QUEUES = 8;
 
 // Division of a 32-bit number by a divisor fixed for the whole launch: a multiply-high and two shifts in
 // place of the long sequence a division compiles to (Granlund & Montgomery, unsigned case).

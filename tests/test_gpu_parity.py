@@ -292,3 +292,20 @@ def test_large_scene_library_defaults(scenes):
     ok = np.isfinite(osums).all(axis=2)
     close = np.isclose(sums, osums, rtol=1e-4, atol=1e-5).all(axis=2)
     assert np.mean(close[ok]) > 0.98                       # a libm rounding may flip a path
+
+
+@pytest.mark.parametrize("slices", ["4", "7"])
+def test_tree_copies_fitted_to_time_slices_find_the_same_hits(slices, monkeypatch):
+    """MIRT_TIME_SLICES keeps several copies of the tree, each fitted to where the moving spheres are during a part of
+    the shutter interval (the other reading of the time0 / time1 arguments BVH::from_world ignores, bvh.rs:24-27);
+    a ray walks the copy of its time.  Same closest hits, bit for bit, at every ray time including both ends."""
+    monkeypatch.setenv("MIRT_TIME_SLICES", slices)
+    g, o = R.ExampleScene("spheres_bvh"), O.Scene("spheres_bvh")
+    try:
+        cam, _ = g.camera()
+        rays = np.concatenate([R.camera_rays(cam, 120, 68, time=0.0), R.camera_rays(cam, 120, 68, time=1.0),
+                               R.camera_rays(cam, 120, 68, time=0.25), random_rays(40000, [-14, 0.0, -14], [14, 3, 14], 41)])
+        assert_same_hits(g, o, rays)
+    finally:
+        g.close()
+        o.close()
