@@ -281,6 +281,21 @@ def main():
             result["cpu_baseline"] = cpu_baseline(a.scene, a.width, a.height, depth)
         else:
             result["cpu_baseline"] = None
+        # The frame of the last timed step as an image: block means against the oracle's frame of the same size
+        # (tests/golden/<scene>_blocks.npz, when the workload is the one the fixture was made for).
+        fixture = ROOT / "tests" / "golden" / f"{a.scene}_blocks.npz"
+        result["golden"] = None
+        if fixture.exists():
+            import numpy as np
+            from raytracing_amd.imageops import compare_with_block_fixture
+            fx = np.load(fixture)
+            if (int(fx["width"]), int(fx["height"]), int(fx["depth"])) == (a.width, a.height, depth):
+                if world > 1:  # (after a reduce to rank 0 the buffer holds the whole frame there)
+                    pass
+                step(0)
+                torch.cuda.synchronize()
+                result["golden"] = compare_with_block_fixture(sums.cpu().numpy(), total_spp, fx)
+                result["golden"]["fixture"] = f"tests/golden/{fixture.name} (oracle, {int(fx['spp'])} spp per pixel)"
         if a.save:  # the frame of the last timed step
             img = rgb.cpu().numpy()
             with open(a.save, "wb") as f:

@@ -27,7 +27,9 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
 import oracle_lib as O  # noqa: E402
+from raytracing_amd.imageops import block_means  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
 GOLD.mkdir(exist_ok=True)
@@ -44,18 +46,6 @@ BLOCKS = {  # name: (scene, width, height, spp per pixel, block edge)
 }
 
 
-def block_means(sums, spp, block):
-    """Mean linear radiance over the finite pixels of each block x block tile, and the poisoned-pixel count."""
-    h, w, _ = sums.shape
-    finite = np.isfinite(sums).all(axis=2)
-    lin = np.where(finite[..., None], sums.astype(np.float64) / spp, 0.0)
-    hb, wb = h // block, w // block
-    lin = lin[:hb * block, :wb * block].reshape(hb, block, wb, block, 3).sum(axis=(1, 3))
-    cnt = finite[:hb * block, :wb * block].reshape(hb, block, wb, block).sum(axis=(1, 3))
-    mean = lin / np.maximum(cnt, 1)[..., None]
-    return mean.astype(np.float32), (block * block - cnt).astype(np.uint8)
-
-
 what = sys.argv[1:] or ["primary"] + list(CONVERGED)
 for name, (scene, w, h, spp, block) in BLOCKS.items():
     if name not in what:
@@ -63,7 +53,22 @@ for name, (scene, w, h, spp, block) in BLOCKS.items():
     t0 = time.time()
     s = O.Scene(scene, scene_seed=1)
     threads = max(1, (len(__import__("os").sched_getaffinity(0))) - 1)
-    _, sums, seg = s.render(w, h, spp, aspect=w / h, seed=SEED, threads=threads)
+    # in passes over sample ranges, with the sums so far kept on disk: a run that is cut short carries on
+    part = Path("/tmp") / f"make_goldens_{name}.npz"
+    sums, seg, done = np.zeros((h, w, 3), np.float64), 0, 0
+    if part.exists():
+        z = np.load(part)
+        if (int(z["width"]), int(z["height"]), int(z["seed"])) == (w, h, SEED):
+            sums, seg, done = z["sums"], int(z["segments"]), int(z["done"])
+    while done < spp:
+        n = min(16, spp - done)
+        _, pass_sums, pass_seg = s.render(w, h, n, aspect=w / h, seed=SEED, first_sample=done, threads=threads)
+        sums += pass_sums
+        seg += pass_seg
+        done += n
+        np.savez(part, sums=sums, segments=seg, done=done, width=w, height=h, seed=SEED)
+        print(name, done, "of", spp, "spp", round(time.time() - t0, 1), "s", flush=True)
+    sums = sums.astype(np.float32)
     mean, poisoned = block_means(sums, spp, block)
     np.savez_compressed(GOLD / f"{name}.npz", mean=mean, poisoned=poisoned, width=w, height=h, spp=spp, block=block,
                         seed=SEED, scene_seed=1, depth=s.depth, aspect=np.float32(w / h),
