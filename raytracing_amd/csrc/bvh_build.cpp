@@ -214,6 +214,120 @@ struct Refit {
 
 }  // namespace
 
+namespace {
+
+struct Widen {
+  const std::vector<HostNode>& in;
+  std::vector<WideNode>& out;
+  struct Kid {
+    uint32_t ref;
+    Box box;
+  };
+  static bool inner(uint32_t ref) { return !(ref & 0x80000000u); }
+  // returns the reference that stands for `ref` in the wide tree, and the height below it
+  uint32_t convert(uint32_t ref, uint32_t& height) {
+    height = 0;
+    if (!inner(ref)) return ref;
+    Kid kids[4];
+    int n = 0;
+    auto take = [&](const HostNode& nd) {
+      if (nd.left != 0xFFFFFFFFu) {
+        Kid& k = kids[n++];
+        k.ref = nd.left;
+        for (int a = 0; a < 3; ++a) { k.box.mn[a] = nd.lmin[a]; k.box.mx[a] = nd.lmax[a]; }
+      }
+      if (nd.right != 0xFFFFFFFFu) {
+        Kid& k = kids[n++];
+        k.ref = nd.right;
+        for (int a = 0; a < 3; ++a) { k.box.mn[a] = nd.rmin[a]; k.box.mx[a] = nd.rmax[a]; }
+      }
+    };
+    take(in[ref]);
+    while (n < 4) {
+      int open = -1;
+      float largest = -1.0f;
+      for (int i = 0; i < n; ++i)
+        if (inner(kids[i].ref) && kids[i].box.half_area() > largest) { largest = kids[i].box.half_area(); open = i; }
+      if (open < 0) break;
+      // the opened child's children take its place and the next free slot (n <= 3 here, so both fit)
+      const HostNode& nd = in[kids[open].ref];
+      kids[open] = kids[n - 1];
+      --n;
+      take(nd);
+    }
+    const uint32_t index = (uint32_t)out.size();
+    out.emplace_back();
+    uint32_t refs[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int i = 0; i < n; ++i) {
+      uint32_t h = 0;
+      refs[i] = convert(kids[i].ref, h);
+      height = std::max(height, h);
+    }
+    WideNode& w = out[index];
+    for (int i = 0; i < 4; ++i) {
+      w.child[i] = refs[i];
+      w.pad[i] = 0;
+      for (int a = 0; a < 3; ++a) {
+        w.lo[a][i] = i < n ? kids[i].box.mn[a] : std::numeric_limits<float>::infinity();
+        w.hi[a][i] = i < n ? kids[i].box.mx[a] : -std::numeric_limits<float>::infinity();
+      }
+    }
+    ++height;
+    return index;
+  }
+};
+
+}  // namespace
+
+WideBvh widen_bvh(const std::vector<HostNode>& nodes, uint32_t root_ref) {
+  WideBvh out;
+  out.nodes.reserve(nodes.size() / 2 + 1);
+  Widen w{nodes, out.nodes};
+  out.root_ref = w.convert(root_ref, out.height);
+  return out;
+}
+
+std::vector<QuantNode> quantize_wide(const WideBvh& wide) {
+  std::vector<QuantNode> out(wide.nodes.size());
+  for (size_t i = 0; i < wide.nodes.size(); ++i) {
+    const WideNode& w = wide.nodes[i];
+    QuantNode& q = out[i];
+    std::memset(&q, 0, sizeof(q));
+    q.exps = 0;
+    for (int c = 0; c < 4; ++c) q.child[c] = w.child[c];
+    for (int a = 0; a < 3; ++a) {
+      float mn = std::numeric_limits<float>::infinity(), mx = -std::numeric_limits<float>::infinity();
+      for (int c = 0; c < 4; ++c)
+        if (w.child[c] != 0xFFFFFFFFu) { mn = std::min(mn, w.lo[a][c]); mx = std::max(mx, w.hi[a][c]); }
+      if (!(mn <= mx)) { mn = 0.0f; mx = 0.0f; }  // (no children: cannot happen for a built tree)
+      q.origin[a] = mn;
+      // the smallest power-of-two spacing with 255 steps reaching the far side; one more when rounding gets in the way
+      int e = 0;
+      (void)std::frexp(std::max((mx - mn) / 255.0f, std::numeric_limits<float>::min()), &e);  // 2^(e-1) <= x < 2^e
+      for (;; ++e) {
+        if (e < -125) e = -125;
+        const float step = std::ldexp(1.0f, e);
+        bool ok = true;
+        for (int c = 0; c < 4 && ok; ++c) {
+          if (w.child[c] == 0xFFFFFFFFu) { q.lo[a][c] = 255; q.hi[a][c] = 0; continue; }
+          float lo = std::floor((w.lo[a][c] - mn) / step);
+          lo = std::min(std::max(lo, 0.0f), 255.0f);
+          while (lo > 0.0f && std::fmaf(lo, step, mn) > w.lo[a][c]) lo -= 1.0f;  // (decoded exactly as the device does)
+          float hi = std::ceil((w.hi[a][c] - mn) / step);
+          hi = std::max(hi, 0.0f);
+          while (hi <= 255.0f && std::fmaf(hi, step, mn) < w.hi[a][c]) hi += 1.0f;
+          if (hi > 255.0f || std::fmaf(lo, step, mn) > w.lo[a][c]) { ok = false; break; }
+          q.lo[a][c] = (uint8_t)lo;
+          q.hi[a][c] = (uint8_t)hi;
+        }
+        if (ok || e >= 127) break;
+      }
+      q.exps |= (uint32_t)(e + 127) << (8 * a);  // the bits of 2^e are (e + 127) << 23
+    }
+  }
+  return out;
+}
+
 void refit_bvh(std::vector<HostNode>& nodes, uint32_t root_ref, const std::vector<BuildPrim>& prims) {
   Refit r{nodes, prims};
   (void)r.fit(root_ref);

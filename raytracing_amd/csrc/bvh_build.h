@@ -43,6 +43,46 @@ struct BuiltBvh {
 // (a smaller tree).
 BuiltBvh build_bvh(std::vector<BuildPrim>& prims, uint32_t max_height, uint32_t leaf_max, float step_cost = 1.0f);
 
+// Four-child node, 128 bytes = 8 quads, for trees walked from global memory: one fetch decides four children, so a
+// ray takes fewer than half as many dependent fetches to reach its leaves.
+//   q0..q2 = children's min x, min y, min z   q3..q5 = max x, max y, max z   q6 = child refs   q7 = unused
+// A missing child has ref 0xFFFFFFFF and an inverted box.
+struct WideNode {
+  float lo[3][4];
+  float hi[3][4];
+  uint32_t child[4];
+  uint32_t pad[4];
+};
+static_assert(sizeof(WideNode) == 128, "a wide node is two 64-byte lines");
+
+struct WideBvh {
+  std::vector<WideNode> nodes;
+  uint32_t root_ref = 0xFFFFFFFFu;
+  uint32_t height = 0;  // inner nodes on the longest root-to-leaf path
+};
+
+// Folds a two-child tree into four-child nodes: every node takes its two children and then, twice, opens the child
+// with the largest surface area that is an inner node.  Leaves and their primitives stay as they are.
+WideBvh widen_bvh(const std::vector<HostNode>& nodes, uint32_t root_ref);
+
+// The four-child node as the device reads it: one 64-byte line.  The children's boxes are stored as 8-bit offsets
+// on a grid that starts at the node's own minimum corner and has a power-of-two spacing per axis,
+//   lo = fma(q_lo, 2^e, origin)   hi = fma(q_hi, 2^e, origin)      (the same fused operation on the device),
+// rounded outwards, so a decoded box always contains the child's true box: walks never miss, they only take the odd
+// extra step.  Four 16-byte loads per step instead of seven; a walk from global memory pays for every load.
+//   q0 = origin.xyz, bits(ex | ey << 8 | ez << 16)  (biased exponents of the grid spacing)
+//   q1 = lo.x[4] lo.y[4] lo.z[4] hi.x[4] as bytes   q2 = hi.y[4] hi.z[4] as bytes, 8 bytes unused   q3 = child refs
+struct QuantNode {
+  float origin[3];
+  uint32_t exps;
+  uint8_t lo[3][4];
+  uint8_t hi[3][4];
+  uint32_t pad[2];
+  uint32_t child[4];
+};
+static_assert(sizeof(QuantNode) == 64, "a quantised node is one 64-byte line");
+std::vector<QuantNode> quantize_wide(const WideBvh& wide);
+
 // Recomputes every child box of a built tree (same nodes, same leaves) from other primitive boxes: `prims` in tree
 // order, as the build left them.  Used to fit one tree to the primitives' positions in several slices of time.
 void refit_bvh(std::vector<HostNode>& nodes, uint32_t root_ref, const std::vector<BuildPrim>& prims);

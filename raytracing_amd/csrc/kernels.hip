@@ -364,11 +364,28 @@ __device__ __forceinline__ void walk_begin(Walk& w, const Ray& r, uint32_t root,
   w.steps = 0;
 }
 
-// One step down the tree (w.cur must be an inner node): both child boxes are tested, the nearer one that
-// is hit becomes the reference in hand, the other one waits on the stack.  `stack` is this lane's column
-// of an LDS stack whose rows are `stride` entries apart.
-template <bool COMPACT, class Slot>
-__device__ __forceinline__ void node_step(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride) {
+// A lane's traversal stack: a column of an LDS array whose rows are `stride` entries apart.  Scenes walked from
+// global memory have four-child nodes and deeper stacks: the levels beyond the LDS rows live in global memory
+// (`over`, rows RENDER_THREADS apart), which only a very unbalanced tree ever reaches.
+template <bool COMPACT>
+struct WalkStack {
+  using Slot = typename std::conditional<COMPACT, uint16_t, uint32_t>::type;
+  Slot* lds;
+  uint32_t* over;  // this lane's column of the block's overflow rows (unused when COMPACT)
+  __device__ __forceinline__ void set(uint32_t k, uint32_t v) const {
+    if (COMPACT || k < (uint32_t)WIDE_LDS_STACK) lds[k * RENDER_THREADS] = (Slot)v;
+    else over[(size_t)(k - WIDE_LDS_STACK) * RENDER_THREADS] = v;
+  }
+  __device__ __forceinline__ uint32_t get(uint32_t k) const {
+    if (COMPACT || k < (uint32_t)WIDE_LDS_STACK) return lds[k * RENDER_THREADS];
+    return over[(size_t)(k - WIDE_LDS_STACK) * RENDER_THREADS];
+  }
+};
+
+// One step down a two-child tree (w.cur must be an inner node): both child boxes are tested, the nearer one that
+// is hit becomes the reference in hand, the other one waits on the stack.
+template <bool COMPACT>
+__device__ __forceinline__ void node_step(Walk& w, const SceneTables& tb, float t_min, const WalkStack<COMPACT>& st) {
   using RC = RefCode<COMPACT>;
   const float4* n = tb.nodes + (w.node_base + 4 * (size_t)w.cur);
   const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
@@ -378,21 +395,67 @@ __device__ __forceinline__ void node_step(Walk& w, const SceneTables& tb, float 
   const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
   if (hl && hr) {
     const bool left_first = tl <= tr;
-    stack[(w.sp++) * stride] = (Slot)(left_first ? right : left);
+    st.set(w.sp++, left_first ? right : left);
     w.cur = left_first ? left : right;
   } else if (hl) {
     w.cur = left;
   } else if (hr) {
     w.cur = right;
   } else {
-    w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
+    w.cur = w.sp ? st.get(--w.sp) : RC::NONE;
+  }
+}
+
+// One step down a four-child tree (layout: QuantNode in bvh_build.h, one 64-byte line): the four boxes are
+// decoded and tested, the children that are hit are put in order of their entry distance, the nearest becomes the
+// reference in hand and the others wait on the stack, nearest on top.
+__device__ __forceinline__ float byte_of(uint32_t word, int k) { return (float)((word >> (8 * k)) & 255u); }  // v_cvt_f32_ubyteK
+__device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float t_min, const WalkStack<false>& st) {
+  const float4* n = tb.nodes + 4 * (size_t)w.cur;
+  const float4 q0 = n[0], q1 = n[1], q2 = n[2], rq = n[3];
+  uint32_t r0 = __float_as_uint(rq.x), r1 = __float_as_uint(rq.y), r2 = __float_as_uint(rq.z), r3 = __float_as_uint(rq.w);
+  const uint32_t exps = __float_as_uint(q0.w);
+  const float sx = __uint_as_float((exps & 255u) << 23), sy = __uint_as_float(((exps >> 8) & 255u) << 23),
+              sz = __uint_as_float(((exps >> 16) & 255u) << 23);
+  const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z),
+                 hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+  // lo = fma(byte, 2^e, origin): the operation the builder checked its rounding with
+#define MIRT_CHILD_BOX(k)                                                                                       \
+  v3(__builtin_fmaf(byte_of(lox, k), sx, q0.x), __builtin_fmaf(byte_of(loy, k), sy, q0.y),                       \
+     __builtin_fmaf(byte_of(loz, k), sz, q0.z)),                                                                 \
+      v3(__builtin_fmaf(byte_of(hix, k), sx, q0.x), __builtin_fmaf(byte_of(hiy, k), sy, q0.y),                   \
+         __builtin_fmaf(byte_of(hiz, k), sz, q0.z))
+  float t0, t1, t2, t3;
+  const bool h0 = slab(MIRT_CHILD_BOX(0), w.r.o, w.inv, t_min, w.best_t, t0) && r0 != REF_NONE;
+  const bool h1 = slab(MIRT_CHILD_BOX(1), w.r.o, w.inv, t_min, w.best_t, t1) && r1 != REF_NONE;
+  const bool h2 = slab(MIRT_CHILD_BOX(2), w.r.o, w.inv, t_min, w.best_t, t2) && r2 != REF_NONE;
+  const bool h3 = slab(MIRT_CHILD_BOX(3), w.r.o, w.inv, t_min, w.best_t, t3) && r3 != REF_NONE;
+#undef MIRT_CHILD_BOX
+  // entry distances are >= t_min > 0, so their bit patterns order like the numbers; a miss sorts behind every hit
+  uint32_t k0 = h0 ? __float_as_uint(t0) : 0xFFFFFFFFu, k1 = h1 ? __float_as_uint(t1) : 0xFFFFFFFFu;
+  uint32_t k2 = h2 ? __float_as_uint(t2) : 0xFFFFFFFFu, k3 = h3 ? __float_as_uint(t3) : 0xFFFFFFFFu;
+  auto order = [](uint32_t& ka, uint32_t& ra, uint32_t& kb, uint32_t& rb) {
+    const bool swap = kb < ka;
+    const uint32_t k = swap ? kb : ka, r = swap ? rb : ra;
+    kb = swap ? ka : kb; rb = swap ? ra : rb;
+    ka = k; ra = r;
+  };
+  order(k0, r0, k1, r1); order(k2, r2, k3, r3); order(k0, r0, k2, r2); order(k1, r1, k3, r3); order(k1, r1, k2, r2);
+  const uint32_t n_hit = (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
+  if (n_hit == 0u) {
+    w.cur = w.sp ? st.get(--w.sp) : REF_NONE;
+  } else {
+    if (n_hit > 3u) st.set(w.sp++, r3);
+    if (n_hit > 2u) st.set(w.sp++, r2);
+    if (n_hit > 1u) st.set(w.sp++, r1);
+    w.cur = r0;
   }
 }
 
 // Tests the first primitive of the leaf in hand (w.cur must be a leaf other than NONE); the rest of the
 // leaf stays in hand, and after its last primitive the next reference comes off the stack.
-template <int PSTRIDE, bool COMPACT, class Slot>
-__device__ __forceinline__ void prim_step(Walk& w, const SceneTables& tb, float t_min, Slot* stack, uint32_t stride) {
+template <int PSTRIDE, bool COMPACT>
+__device__ __forceinline__ void prim_step(Walk& w, const SceneTables& tb, float t_min, const WalkStack<COMPACT>& st) {
   using RC = RefCode<COMPACT>;
   const uint32_t index = w.cur & RC::MASK;
   float t;
@@ -405,7 +468,7 @@ __device__ __forceinline__ void prim_step(Walk& w, const SceneTables& tb, float 
     }
   }
   if ((w.cur >> RC::SHIFT) & 7u) w.cur += 1u - (1u << RC::SHIFT);  // one fewer left, starting one further
-  else w.cur = w.sp ? stack[(--w.sp) * stride] : RC::NONE;
+  else w.cur = w.sp ? st.get(--w.sp) : RC::NONE;
 }
 
 // Both roots of the sphere quadratic (objects.rs:42-53), or false when the discriminant is negative.
@@ -1074,7 +1137,9 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   total = uniform(total);
   const RenderLds<LDS_SCENE> lds(smem, A);
   const SceneTables tb = lds.tables(A);
-  typename RenderLds<LDS_SCENE>::Slot* const stack = lds.stack;
+  // (the overflow rows of the block: [level][thread])
+  const WalkStack<LDS_SCENE> st{lds.stack, LDS_SCENE || A->stack_overflow == nullptr ? nullptr
+                                               : A->stack_overflow + (size_t)blockIdx.x * A->overflow_levels * THREADS + threadIdx.x};
   const uint32_t region = blockIdx.x;
   const uint32_t lane = lane_id();
   const uint32_t cap = A->rc.region_cap;
@@ -1109,7 +1174,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   for (;;) {
     // done: the closest hit is known.  spent: the round's budget is used up and the walk is put aside.
     const bool finished = slot != NO_SLOT && w.cur == RC::NONE;
-    const bool spent = !LDS_SCENE && step_budget != 0u && slot != NO_SLOT && !finished && w.steps >= step_budget;
+    const bool spent = !LDS_SCENE && step_budget != 0u && slot != NO_SLOT && !finished && w.steps >= step_budget &&
+                       w.sp <= SAVE_STACK;  // (a stack deeper than a save entry holds walks on)
     const bool done = finished || spent;
     const unsigned long long m_done = __ballot(done);
     const unsigned long long m_out = m_done | __ballot(slot == NO_SLOT);
@@ -1138,8 +1204,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
           sv[0] = make_uint4(w.cur, w.sp, w.best_ref, w.best_order);
           sv[1] = make_uint4(__float_as_uint(w.best_t), w.best_material, w.best_face, 0u);
           for (uint32_t k = 0; k < w.sp; k += 4u)
-            sv[2u + (k >> 2)] = make_uint4(stack[k * THREADS], stack[(k + 1u) * THREADS], stack[(k + 2u) * THREADS],
-                                           stack[(k + 3u) * THREADS]);
+            sv[2u + (k >> 2)] = make_uint4(st.get(k), k + 1u < w.sp ? st.get(k + 1u) : 0u, k + 2u < w.sp ? st.get(k + 2u) : 0u,
+                                           k + 3u < w.sp ? st.get(k + 3u) : 0u);
         } else {
           q = -1;
           w.steps = 0;  // walks another budget's worth before it asks again
@@ -1200,8 +1266,10 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
               w.best_t = __uint_as_float(b.x); w.best_material = b.y; w.best_face = b.z;
               for (uint32_t k = 0; k < w.sp; k += 4u) {
                 const uint4 e = sv[2u + (k >> 2)];
-                stack[k * THREADS] = e.x; stack[(k + 1u) * THREADS] = e.y;
-                stack[(k + 2u) * THREADS] = e.z; stack[(k + 3u) * THREADS] = e.w;
+                st.set(k, e.x);
+                if (k + 1u < w.sp) st.set(k + 1u, e.y);
+                if (k + 2u < w.sp) st.set(k + 2u, e.z);
+                if (k + 3u < w.sp) st.set(k + 3u, e.w);
               }
             }
           }
@@ -1212,7 +1280,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
     if (COUNT) ts = clock64();
     while (!(w.cur & RC::LEAF)) {
       if (COUNT) { ++work.nodes; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_nodes; }
-      node_step<LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+      if constexpr (LDS_SCENE) node_step<true>(w, tb, kTMin, st);
+      else wide_step(w, tb, kTMin, st);
       if (!LDS_SCENE) ++w.steps;
       // the last few lanes still on their way down do not keep the others waiting
       if ((uint32_t)__popcll(__ballot(!(w.cur & RC::LEAF))) < node_min) break;
@@ -1220,7 +1289,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
     if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_NODES] += now - ts; ts = now; }
     if ((w.cur & RC::LEAF) && w.cur != RC::NONE) {
       if (COUNT) { ++work.prims; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_prims; }
-      prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, stack, THREADS);
+      prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, st);
       if (!LDS_SCENE) ++w.steps;
     }
     if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - ts;
@@ -1813,14 +1882,14 @@ RenderConfig plan_render(const DeviceScene& sc) {
   // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes;
   // bookkeeping, tables, then the stacks on a row of their own
   const size_t lds_total = SHARED_BYTES + (scene_bytes + 255) / 256 * 256 + (size_t)depth * RENDER_THREADS * 2;
-  if (lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
+  if (!sc.wide && lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
     cfg.lds_scene = true;
     cfg.stack_depth = depth;
     cfg.lds_bytes = lds_total;
   } else {
     cfg.lds_scene = false;
-    cfg.stack_depth = STACK_DEPTH;
-    cfg.lds_bytes = SHARED_BYTES + (size_t)STACK_DEPTH * RENDER_THREADS * 4;
+    cfg.stack_depth = WIDE_LDS_STACK;
+    cfg.lds_bytes = SHARED_BYTES + (size_t)WIDE_LDS_STACK * RENDER_THREADS * 4;
   }
   cfg.refill_min = 32;
   cfg.node_min = 16;

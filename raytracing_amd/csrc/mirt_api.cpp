@@ -62,6 +62,7 @@ struct mirt_context {
   DeviceBuffer paths[2];
   DeviceBuffer queues;
   DeviceBuffer saves;
+  DeviceBuffer overflow;
   DeviceBuffer state;
   DeviceBuffer args;
   DeviceBuffer work;
@@ -595,6 +596,41 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     n_slices = 1;
   }
   if (s.bvh_height > (uint32_t)STACK_DEPTH - 2) return fail(ctx, MIRT_ERR_UNSUPPORTED, "BVH taller than the traversal stack");
+  // A scene that will be walked from global memory gets four-child nodes: every step is a dependent fetch there,
+  // and a ray reaches its leaves in fewer than half as many.
+  bool wide = false;
+  {
+    DeviceScene probe{};
+    probe.n_nodes = n_nodes;
+    probe.n_slices = n_slices;
+    probe.bvh_height = s.bvh_height;
+    probe.n_prims = (uint32_t)build.size();
+    probe.n_chain_ops = d.n_chain_ops;
+    probe.n_chains = d.n_chains;
+    probe.n_materials = d.n_materials;
+    probe.n_textures = d.n_textures;
+    probe.n_lights = d.n_lights;
+    probe.n_light_groups = d.n_light_groups;
+    wide = !plan_render(probe).lds_scene && n_nodes != 0;
+  }
+  if (wide) {
+    if (host_nodes.empty()) {  // the slices above did not need them; built on the device or already uploaded
+      host_nodes.resize(n_nodes);
+      MIRT_HIP(ctx, hipMemcpy(host_nodes.data(), s.nodes.ptr, (size_t)n_nodes * sizeof(HostNode), hipMemcpyDeviceToHost));
+    }
+    const WideBvh w = widen_bvh(host_nodes, root_ref);
+    host_nodes.clear();
+    host_nodes.shrink_to_fit();
+    if (3 * w.height + 1 > (uint32_t)WIDE_MAX_STACK) return fail(ctx, MIRT_ERR_UNSUPPORTED, "BVH taller than the traversal stack");
+    s.nodes.release();
+    MIRT_HIP(ctx, upload(s.nodes, quantize_wide(w)));
+    root_ref = w.root_ref;
+    n_nodes = (uint32_t)w.nodes.size();
+    s.bvh_height = w.height;
+    n_slices = 1;
+    if (std::getenv("MIRT_VERBOSE"))
+      std::fprintf(stderr, "mirt: folded into %u four-child nodes, height %u\n", n_nodes, s.bvh_height);
+  }
   if (std::getenv("MIRT_VERBOSE"))
     std::fprintf(stderr, "mirt: %s BVH build of %zu primitives: %.1f ms, %u nodes, height %u, %u time slice(s)\n",
                  builder == MIRT_BUILD_DEVICE_MORTON ? "device (Morton order)" : "host (surface-area)", build.size(),
@@ -709,6 +745,7 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   v.n_slices = n_slices;
   v.slice_time0 = d.time0;
   v.slice_scale = n_slices > 1 ? (float)n_slices / (d.time1 - d.time0) : 0.0f;
+  v.wide = wide ? 1u : 0u;
   v.bvh_height = s.bvh_height;
   v.n_chains = d.n_chains;
   v.prims = s.prims.as<float4>();
@@ -868,13 +905,22 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   // Large scenes (from 2^18 primitives): a ray takes at most `budget` steps per round; longer walks are put aside
   // and go on in the next round, so the few rays that graze such a scene for thousands of steps no longer hold up
   // every round.  Smaller scenes have no such rays and would only pay for the bookkeeping.
+  args.stack_overflow = nullptr;
+  args.overflow_levels = 0;
+  if (scene->view.wide && 3 * scene->view.bvh_height + 1 > (uint32_t)WIDE_LDS_STACK) {
+    // (a very unbalanced tree: the deep end of the stacks lives in global memory)
+    if (job.fixed_workspace) return fail(ctx, MIRT_ERR_UNSUPPORTED, "this scene's tree needs stack rows the fixed workspace does not hold");
+    args.overflow_levels = 3 * scene->view.bvh_height + 1 - (uint32_t)WIDE_LDS_STACK;
+    MIRT_HIP(ctx, ctx->overflow.ensure((size_t)N_REGIONS * args.overflow_levels * RENDER_THREADS * 4));
+    args.stack_overflow = ctx->overflow.as<uint32_t>();
+  }
   args.step_budget = 0;
   args.save_cap = ws.save_cap;
   args.saves = ws.saves;
   if (!cfg.lds_scene && !job.rays && (scene->n_prims >= (1u << 18) || std::getenv("MIRT_STEP_BUDGET"))) {
-    // (1 M spheres: 256 steps is best, +22 % over walking a thirty-second of the scene's diagonal per round and +85 %
-    // over whole rays; 10 M: 1024, +21 % and +144 % -- deeper trees, longer walks, dearer rounds)
-    long budget = scene->n_prims >= (1u << 22) ? 1024 : 256;
+    // (a step is one four-child node or one primitive test.  1 M spheres: 128 to 256 steps is best, +22 % over
+    // walking a thirty-second of the scene's diagonal per round and +85 % over whole rays; 10 M: 256 to 512)
+    long budget = 256;
     if (const char* e = std::getenv("MIRT_STEP_BUDGET")) budget = std::strtol(e, nullptr, 10);  // tuning aid; 0 = whole rays
     if (budget > 0) args.step_budget = (uint32_t)std::min<long>(budget, 1 << 30);
   }

@@ -34,6 +34,12 @@ __host__ __device__ inline uint32_t make_material_word(uint32_t queue, uint32_t 
 // Traversal stack entries per lane (kept in LDS).  The host builder never
 // produces a tree taller than STACK_DEPTH - 2.
 constexpr int STACK_DEPTH = 32;
+// Scenes walked from global memory have four-child nodes (WideNode, bvh_build.h): a step may leave three children
+// waiting, so the stack holds up to 3 * height + 1 entries.  The first WIDE_LDS_STACK of them are kept in LDS (1024
+// lanes x 4 bytes each), deeper ones in global memory.  A walk put aside carries up to SAVE_STACK entries.
+constexpr int WIDE_LDS_STACK = 38;
+constexpr int WIDE_MAX_STACK = 3 * (STACK_DEPTH - 2) + 1;
+constexpr uint32_t SAVE_STACK = 40;
 constexpr int RENDER_THREADS = 1024;    // render: one block per region, a CU's worth of waves
 constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
@@ -106,6 +112,7 @@ struct DeviceScene {
   // during slice s of [slice_time0, slice_time0 + n_slices / slice_scale]: a ray walks the copy of its time.
   uint32_t n_slices;
   float slice_time0, slice_scale;
+  uint32_t wide;  // nodes are four-child WideNodes (the scene is walked from global memory)
 
   const float4* prims;  // primitive records, layout above
   const uint2* prim_ids;
@@ -215,8 +222,8 @@ struct RenderConst {
 // Shading queue q of region s holds whole path records (the walk moves a finished ray's record there, hit
 // included) at queues[4 * (s * N_QUEUES + q) * region_cap ...]: shading reads a queue front to back.
 // A walk put aside: (reference in hand, stack entries in use, best ref, best order), (best t, best material word,
-// best box side, -), then the STACK_DEPTH stack entries, four to a quad.
-constexpr uint32_t SAVE_QUADS = 2 + STACK_DEPTH / 4;
+// best box side, -), then up to SAVE_STACK stack entries, four to a quad.
+constexpr uint32_t SAVE_QUADS = 2 + SAVE_STACK / 4;
 constexpr uint32_t MAX_SAMPLE_INDEX = (1u << 24) - 1u;
 constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 
@@ -227,7 +234,7 @@ constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 constexpr uint32_t STATIC_POOL_PATHS = 65536;
 constexpr uint32_t STATIC_SAVE_CAP = 32;  // walks put aside per region and round in the fixed workspace
 constexpr size_t STATIC_CONTROL_BYTES = 4096;
-constexpr size_t STATIC_SAVE_BYTES = (size_t)N_REGIONS * 2 * STATIC_SAVE_CAP * 16 * (2 + STACK_DEPTH / 4);
+constexpr size_t STATIC_SAVE_BYTES = (size_t)N_REGIONS * 2 * STATIC_SAVE_CAP * 16 * (2 + 40 / 4);
 constexpr size_t STATIC_WORKSPACE_BYTES =
     STATIC_CONTROL_BYTES + (size_t)STATIC_POOL_PATHS * 64 * (2 + N_QUEUES) + STATIC_SAVE_BYTES;
 // Address of the current device's copy (`device` must be the current device); looked up once per device.
@@ -265,6 +272,10 @@ struct RenderArgs {
   uint32_t step_budget;
   uint32_t save_cap;
   uint4* saves;
+  // stack levels beyond WIDE_LDS_STACK: overflow_levels rows of RENDER_THREADS entries per block, or null when the
+  // tree is flat enough never to need them
+  uint32_t* stack_overflow;
+  uint32_t overflow_levels;
   // Tracing caller-supplied rays instead of rendering (rays != nullptr): rc.total_paths rays come from `rays`,
   // each is walked once, and what ray g hit goes to hit_type[g], hit_object[g], hit_t[g] (and hit_records).
   const mirt_ray* rays;

@@ -2,7 +2,7 @@
 # usage: bash tools/gpu_big_profile.sh [half=1581] [spp=8] [tag=r2_big]
 set -e
 R=$GRAFT_REPO_ROOT
-HALF=${1:-1581}; SPP=${2:-8}; TAG=${3:-r2_big}
+HALF=${1:-1581}; SPP=${2:-64}; TAG=${3:-r2_big}
 O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
