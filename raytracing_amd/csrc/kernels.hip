@@ -956,18 +956,21 @@ __device__ __forceinline__ void pixel_of(uint32_t idx, uint32_t width, uint32_t 
 // ---- render -----------------------------------------------------------------------
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
-// Block-shared bookkeeping of one region's loop, written by thread 0 between barriers.
-struct RenderShared {
+// Bookkeeping of one region's loop.  A region belongs to one wave, so nothing here is touched by two waves: it lives
+// in LDS only because the phases of a round are separate functions.  Written by the wave's lane 0 between phases.
+struct WaveShared {
   uint32_t n_fresh;                     // camera paths started this round, in the slots after the survivors
   uint32_t first_new_lo, first_new_hi;  // number of the first of them among the render's paths
   uint32_t next_work;                   // next slot to hand out to the walk
   uint32_t queue_n[N_QUEUES];           // entries in the region's material queues
   uint32_t n_next;                      // survivors written to the other buffer so far
-  uint32_t shade_next;                  // next batch of 64 queue entries to hand out to a shading wave
-  uint32_t late_next;                   // the same for the second shading pass
   uint32_t late_n[N_QUEUES];            // entries appended to each queue for the second shading pass
   uint32_t n_saved;                     // walks put aside this round (entries of the region's save area in use)
-  uint32_t pad[2];
+  uint32_t pad[10];
+};
+static_assert(sizeof(WaveShared) == 128, "one LDS row half per wave");
+struct RenderShared {
+  WaveShared wave[RENDER_THREADS / 64];
   MediumEntry media[MIRT_MAX_MEDIA];
 };
 constexpr size_t SHARED_BYTES = (sizeof(RenderShared) + 255) / 256 * 256;  // the node array starts on an LDS row
@@ -993,6 +996,19 @@ __device__ __forceinline__ ConstArgs pinned(const RenderArgs* p) {
 typedef __attribute__((address_space(3))) float4* LdsQuads;
 __device__ __forceinline__ float4* lds_base(uint32_t address) {
   return (float4*)(LdsQuads)(uintptr_t)uniform(address);
+}
+
+// A wave owns a region of the path pool and takes it through the rounds on its own: the waves of a block share
+// the staged scene and nothing else, and after staging no wave ever waits for another one.
+__device__ __forceinline__ uint32_t wave_in_block() { return uniform(threadIdx.x >> 6); }
+__device__ __forceinline__ uint32_t region_of_wave(ConstArgs A) { return blockIdx.x * A->waves_per_block + wave_in_block(); }
+// Between the phases of a round: what the wave's lanes wrote (path records in global memory, counters in LDS) is
+// read by other lanes of the same wave.  The waves of a block run on one CU and share its vector cache, so
+// waiting for the writes to complete is all it takes; no other wave is involved.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // Dynamic shared memory of the render kernel: [RenderShared][nodes][48-byte primitive records][chain ops]
@@ -1038,13 +1054,12 @@ struct RenderLds {
 template <bool COUNT>
 __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint32_t n_surv, uint32_t n_fresh,
                                          uint64_t first_new) {
-  constexpr int THREADS = RENDER_THREADS;
   ConstArgs A = pinned(args);
   odd = uniform(odd) != 0;
   n_surv = uniform(n_surv);
   n_fresh = uniform(n_fresh);
   first_new = ((uint64_t)uniform((uint32_t)(first_new >> 32)) << 32) | uniform((uint32_t)first_new);
-  const uint32_t region = blockIdx.x;
+  const uint32_t region = region_of_wave(A);
   const uint32_t width = A->rc.width, height = A->rc.height, first_sample = A->rc.first_sample;
   const uint32_t key0 = A->rc.key0, key1 = A->rc.key1;
   const uint32_t n_groups = A->rc.n_groups, group_stride = A->rc.group_stride;
@@ -1069,7 +1084,7 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
   // path number = pass * pixels + place in the pass; the one long division is done once for the block
   const uint32_t first_pass = (uint32_t)(first_new / pixels);
   const uint32_t first_place = (uint32_t)(first_new - (uint64_t)first_pass * pixels);
-  for (uint32_t k = threadIdx.x; k < n_fresh; k += THREADS) {
+  for (uint32_t k = lane_id(); k < n_fresh; k += 64u) {
     const size_t i = n_surv + k;
     const uint32_t place = first_place + k;  // < 2^31 + 2^27
     const uint32_t more_passes = fast_div(place, by_pixels);
@@ -1129,7 +1144,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
                                        uint32_t* segments_out) {
   constexpr int THREADS = RENDER_THREADS;
   float4* const smem = lds_base(lds_arg);
-  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  WaveShared& sh = reinterpret_cast<RenderShared*>(smem)->wave[wave_in_block()];
   using RC = RefCode<LDS_SCENE>;
   constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
   ConstArgs A = pinned(args);
@@ -1140,7 +1155,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   // (the overflow rows of the block: [level][thread])
   const WalkStack<LDS_SCENE> st{lds.stack, LDS_SCENE || A->stack_overflow == nullptr ? nullptr
                                                : A->stack_overflow + (size_t)blockIdx.x * A->overflow_levels * THREADS + threadIdx.x};
-  const uint32_t region = blockIdx.x;
+  const uint32_t region = region_of_wave(A);
   const uint32_t lane = lane_id();
   const uint32_t cap = A->rc.region_cap;
   float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
@@ -1310,17 +1325,18 @@ template <bool COUNT>
 __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg, bool odd, uint32_t total, Work* work_out,
                                        uint32_t* segments_out) {
   float4* const smem = lds_base(lds_arg);
-  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  WaveShared& sh = reinterpret_cast<RenderShared*>(smem)->wave[wave_in_block()];
   ConstArgs A = pinned(args);
   odd = uniform(odd) != 0;
   total = uniform(total);
   const RenderLds<true> lds(smem, A);
   const SceneTables tb = lds.tables(A);
+  const uint32_t region = region_of_wave(A);
   const uint32_t lane = lane_id();
   const uint32_t cap = A->rc.region_cap;
   const uint32_t n_prims = A->sc.n_prims;
-  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)blockIdx.x * cap;
-  float4* const region_queues = A->queues + 4 * (size_t)blockIdx.x * N_QUEUES * cap;
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
+  float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   uint32_t segments = 0;
   long long ts = 0;
   Work work{};
@@ -1391,13 +1407,14 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
 template <bool COUNT, bool LDS_SCENE>
 __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_arg, bool odd) {
   float4* const smem = lds_base(lds_arg);
-  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  RenderShared& block = *reinterpret_cast<RenderShared*>(smem);
+  WaveShared& sh = block.wave[wave_in_block()];
   constexpr int PSTRIDE = LDS_SCENE ? (int)PRIM_QUADS_LDS : (int)PRIM_QUADS;
   ConstArgs A = pinned(args);
   odd = uniform(odd) != 0;
   const RenderLds<LDS_SCENE> lds(smem, A);
   const SceneTables tb = lds.tables(A);
-  const uint32_t region = blockIdx.x;
+  const uint32_t region = region_of_wave(A);
   const uint32_t lane = lane_id();
   ShadeTables sc = MIRT_SHADE_TABLES(A->sc);
   if (LDS_SCENE) {  // the block's own copies
@@ -1424,8 +1441,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
   // what stays in its queue and appends the rest (written back with the medium hit) to the queue of the
   // medium's material; the second shades those.  Every wave then runs one material's code with full lanes.
   for (uint32_t pass = 0; pass < 2u; ++pass) {
-    // The entries of the queues are cut into batches of 64, numbered queue after queue; a wave takes the
-    // next batch whenever it has finished one, so no wave is left with the expensive ones.
+    // The entries of the queues are cut into batches of 64, numbered queue after queue.
     uint32_t first[N_QUEUES], count[N_QUEUES], last_batch[N_QUEUES];
     uint32_t n_batches = 0;
 #pragma unroll
@@ -1436,11 +1452,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       n_batches += (count[k] + 63u) >> 6;
       last_batch[k] = n_batches;
     }
-    for (;;) {
-      uint32_t batch = 0;
-      if (lane == 0) batch = atomicAdd(pass == 0 ? &sh.shade_next : &sh.late_next, 1u);
-      batch = uniform(batch);
-      if (batch >= n_batches) break;
+    for (uint32_t batch = 0; batch < n_batches; ++batch) {
       uint32_t q = 0, n_q = count[0], e0 = batch << 6, from = first[0];
 #pragma unroll
       for (int k = 1; k < N_QUEUES; ++k)
@@ -1469,7 +1481,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
           uint32_t material = 0;
           const uint32_t surface = ref;
           Rng mrng = rng_begin(pixel, sample, bounce, STAGE_MEDIA, rc.key0, rc.key1);
-          closest_media(n_media, tb, gt, sh.media, r, kTMin, mrng, ref, t, material);
+          closest_media(n_media, tb, gt, block.media, r, kTMin, mrng, ref, t, material);
           if (ref != surface) {
             const uint32_t to_q = (uint32_t)queue_of(material);
             if (to_q != q) {  // another material's code: goes to the end of that queue, for the second pass
@@ -1493,7 +1505,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         } else if (ref == REF_NONE) {
           term = v3(rc.background[0], rc.background[1], rc.background[2]);  // renderer.rs:187-189
         } else {
-          const Hit h = hit_record<PSTRIDE>(tb, sh.media, ref, r, t, __float_as_uint(r3.z));
+          const Hit h = hit_record<PSTRIDE>(tb, block.media, ref, r, t, __float_as_uint(r3.z));
           const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
           Rng rng = rng_begin(pixel, sample, bounce, STAGE_SHADE, rc.key0, rc.key1);
           // the one texture lookup of the materials that have one (a light's only shows on its front side)
@@ -1566,7 +1578,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       }
     }
     if (n_media == 0 || pass == 1u) break;
-    __syncthreads();  // the appended entries and their records are visible to the whole block
+    wave_sync();  // the appended entries and their records are visible to every lane
   }
 }
 
@@ -1577,9 +1589,9 @@ __device__ __noinline__ void start_rays(const RenderArgs* args, bool odd, uint32
   odd = uniform(odd) != 0;
   n_fresh = uniform(n_fresh);
   first_new = ((uint64_t)uniform((uint32_t)(first_new >> 32)) << 32) | uniform((uint32_t)first_new);
-  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)blockIdx.x * A->rc.region_cap;
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region_of_wave(A) * A->rc.region_cap;
   const mirt_ray* const rays = A->rays;
-  for (uint32_t k = threadIdx.x; k < n_fresh; k += RENDER_THREADS) {
+  for (uint32_t k = lane_id(); k < n_fresh; k += 64u) {
     const uint64_t g = first_new + k;
     const mirt_ray in = rays[g];
     cur[4 * (size_t)k] = make_float4(in.origin[0], in.origin[1], in.origin[2], in.time);
@@ -1593,7 +1605,8 @@ __device__ __noinline__ void start_rays(const RenderArgs* args, bool odd, uint32
 template <bool LDS_SCENE>
 __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_arg, bool odd) {
   float4* const smem = lds_base(lds_arg);
-  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  RenderShared& block = *reinterpret_cast<RenderShared*>(smem);
+  WaveShared& sh = block.wave[wave_in_block()];
   ConstArgs A = pinned(args);
   odd = uniform(odd) != 0;
   const RenderLds<LDS_SCENE> lds(smem, A);
@@ -1604,7 +1617,7 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
   const uint2* const prim_ids = A->sc.prim_ids;
   const uint32_t key0 = A->rc.key0, key1 = A->rc.key1;
   const uint32_t cap = A->rc.region_cap;
-  const float4* const region_queues = A->queues + 4 * (size_t)blockIdx.x * N_QUEUES * cap;
+  const float4* const region_queues = A->queues + 4 * (size_t)region_of_wave(A) * N_QUEUES * cap;
   uint32_t* const hit_type = A->hit_type;
   uint32_t* const hit_object = A->hit_object;
   float* const hit_t = A->hit_t;
@@ -1616,9 +1629,9 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
     sc.textures = reinterpret_cast<const DTexture*>(lds.textures);
   }
   for (uint32_t q = 0; q < N_QUEUES; ++q) {
-    const uint32_t n_q = sh.queue_n[q];
+    const uint32_t n_q = uniform(sh.queue_n[q]);
     const float4* entries = region_queues + 4 * (size_t)q * cap;
-    for (uint32_t e = threadIdx.x; e < n_q; e += RENDER_THREADS) {
+    for (uint32_t e = lane_id(); e < n_q; e += 64u) {
       const float4* const rec = entries + 4 * (size_t)e;
       const float4 r0 = rec[0], r1 = rec[1], r3 = rec[3];
       Ray r;
@@ -1629,7 +1642,7 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
       if (n_media != 0) {
         uint32_t material = 0;
         Rng rng = rng_begin(g, 0, 0, STAGE_MEDIA, key0, key1);
-        closest_media(n_media, tb, gt, sh.media, r, kTMin, rng, ref, t, material);
+        closest_media(n_media, tb, gt, block.media, r, kTMin, rng, ref, t, material);
       }
       uint32_t ti = 0xFFFFFFFFu, oi = 0xFFFFFFFFu;
       if (ref != REF_NONE) {
@@ -1651,7 +1664,7 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
         float4 o0 = make_float4(0.0f, 0.0f, 0.0f, kInf), o1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o2 = o1, o3 = o1;
         o2.z = __uint_as_float(ti); o2.w = __uint_as_float(oi);
         if (ref != REF_NONE) {
-          Hit h = hit_record<PSTRIDE>(tb, sh.media, ref, r, t, __float_as_uint(r3.z));
+          Hit h = hit_record<PSTRIDE>(tb, block.media, ref, r, t, __float_as_uint(r3.z));
           if (h.sphere_uv) sphere_uv(h.on_sphere, h.u, h.v);
           const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
           V3 color = v3(0.0f, 0.0f, 0.0f);
@@ -1673,53 +1686,56 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
   }
 }
 
-// The whole render in one launch.  Block s owns region s of the path pool and stays resident until the
-// render is done: it stages the scene in LDS once, then goes round
-//   start   camera paths in the region's free slots, taking their numbers from a counter all blocks share,
+// The whole render in one launch.  Every wave owns a region of the path pool and stays resident until the
+// render is done.  The block stages the scene in LDS once; from then on each of its waves goes round on its own
+//   start   camera paths in the region's free slots, taking their numbers from a counter all waves share,
 //   walk    every live ray to its closest surface and into the region's queue for the material hit,
 //   shade   queue by queue; survivors go to the first slots of the region's other buffer,
-// until the region has no live path and the counter has run out.  No block waits for another one.
+// until the region has no live path and the counter has run out.  No wave waits for another one, so the waves of
+// a CU drift apart and at any time some of them walk (LDS and arithmetic) while others start or shade (global memory).
 //
 // LDS_SCENE: nodes, primitive records and wrapper chains are staged in LDS, so neither walk nor shade waits
 // on global memory for the scene; otherwise those tables are read from global memory.
 template <bool COUNT, bool LDS_SCENE>
 __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __restrict__ args) {
-  constexpr int THREADS = RENDER_THREADS;
   extern __shared__ float4 smem[];
-  RenderShared& sh = *reinterpret_cast<RenderShared*>(smem);
+  RenderShared& block = *reinterpret_cast<RenderShared*>(smem);
   uint32_t lds_address = (uint32_t)(uintptr_t)(LdsQuads)smem;
   asm volatile("" : "+s"(lds_address));
   {
     ConstArgs A = pinned(args);
-    stage_media(A->sc.n_media, A->sc.media, A->sc.prims, sh.media);
+    const uint32_t threads = A->waves_per_block * 64u;
+    stage_media(A->sc.n_media, A->sc.media, A->sc.prims, block.media);
     if (LDS_SCENE) {
       const RenderLds<true> lds(smem, A);
       const float4 *nodes = A->sc.nodes, *prims = A->sc.prims, *chain_ops = A->sc.chain_ops;
       const float4* chains = A->sc.chains;
       const uint32_t n_node_quads = A->sc.n_nodes * A->sc.n_slices * 4u, n_prim_quads = A->sc.n_prims * PRIM_QUADS_LDS;
       const uint32_t n_chain_ops = A->sc.n_chain_ops, n_chains = A->sc.n_chains;
-      for (uint32_t k = threadIdx.x; k < n_node_quads; k += THREADS) {
+      for (uint32_t k = threadIdx.x; k < n_node_quads; k += threads) {
         float4 q = nodes[k];
         if ((k & 3u) < 2u) q.w = __uint_as_float(RefCode<true>::encode(__float_as_uint(q.w)));  // child refs
         lds.nodes[k] = q;
       }
-      for (uint32_t k = threadIdx.x; k < n_prim_quads; k += THREADS)
+      for (uint32_t k = threadIdx.x; k < n_prim_quads; k += threads)
         lds.prims[k] = prims[(k / PRIM_QUADS_LDS) * PRIM_QUADS + (k % PRIM_QUADS_LDS)];
-      for (uint32_t k = threadIdx.x; k < n_chain_ops; k += THREADS) lds.ops[k] = chain_ops[k];
-      for (uint32_t k = threadIdx.x; k < n_chains * 2u; k += THREADS) lds.chains[k] = chains[k];
+      for (uint32_t k = threadIdx.x; k < n_chain_ops; k += threads) lds.ops[k] = chain_ops[k];
+      for (uint32_t k = threadIdx.x; k < n_chains * 2u; k += threads) lds.chains[k] = chains[k];
       const float4* materials = reinterpret_cast<const float4*>(A->sc.materials);
       const float4* textures = reinterpret_cast<const float4*>(A->sc.textures);
       const float4* lights = reinterpret_cast<const float4*>(A->sc.lights);
       const uint2* groups = A->sc.light_groups;
       const uint32_t n_materials = A->sc.n_materials, n_texture_quads = A->sc.n_textures * 2u;
       const uint32_t n_light_quads = A->sc.n_lights * 2u, n_groups = A->sc.n_light_groups;
-      for (uint32_t k = threadIdx.x; k < n_materials; k += THREADS) lds.materials[k] = materials[k];
-      for (uint32_t k = threadIdx.x; k < n_texture_quads; k += THREADS) lds.textures[k] = textures[k];
-      for (uint32_t k = threadIdx.x; k < n_light_quads; k += THREADS) lds.lights[k] = lights[k];
-      for (uint32_t k = threadIdx.x; k < n_groups; k += THREADS) reinterpret_cast<uint2*>(lds.groups)[k] = groups[k];
+      for (uint32_t k = threadIdx.x; k < n_materials; k += threads) lds.materials[k] = materials[k];
+      for (uint32_t k = threadIdx.x; k < n_texture_quads; k += threads) lds.textures[k] = textures[k];
+      for (uint32_t k = threadIdx.x; k < n_light_quads; k += threads) lds.lights[k] = lights[k];
+      for (uint32_t k = threadIdx.x; k < n_groups; k += threads) reinterpret_cast<uint2*>(lds.groups)[k] = groups[k];
     }
   }
+  __syncthreads();  // the staged scene is complete: the one time the waves of a block wait for each other
 
+  WaveShared& sh = block.wave[wave_in_block()];
   const bool tracing = pinned(args)->rays != nullptr;  // caller-supplied rays instead of camera paths
   const bool small_scene = pinned(args)->sc.n_prims <= SCAN_MAX_PRIMS;  // tested one primitive after the other
   Work work{};
@@ -1727,9 +1743,9 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
   if (COUNT) k_begin = clock64();
   uint32_t segments = 0, rounds = 0;
   uint32_t n_surv = 0;      // the region carries survivors in its slots [0, n_surv)
-  bool exhausted = false;   // the shared counter has handed out the render's last path (thread 0 only)
+  bool exhausted = false;   // the shared counter has handed out the render's last path (lane 0 only)
   for (;;) {
-    if (threadIdx.x == 0) {
+    if (lane_id() == 0) {
       ConstArgs A = pinned(args);
       uint32_t fresh = 0;
       const uint32_t n_free = A->rc.region_cap - n_surv;
@@ -1748,36 +1764,34 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       sh.next_work = 0;
       for (int q = 0; q < N_QUEUES; ++q) { sh.queue_n[q] = 0; sh.late_n[q] = 0; }
       sh.n_next = 0;
-      sh.shade_next = 0;
-      sh.late_next = 0;
       sh.n_saved = 0;
     }
-    __syncthreads();  // also: the staged scene is complete before the first walk
-    const uint32_t n_fresh = sh.n_fresh;
+    wave_sync();
+    const uint32_t n_fresh = uniform(sh.n_fresh);
     const uint32_t total = n_surv + n_fresh;
     if (total == 0) break;  // nothing alive and nothing left to start: the region is done
     const bool odd = (rounds & 1u) != 0;  // the region's two buffers swap roles every round
     ++rounds;
 
     if (COUNT) ts = clock64();
-    if (tracing) start_rays(args, odd, n_fresh, ((uint64_t)sh.first_new_hi << 32) | sh.first_new_lo);
-    else start_paths<COUNT>(args, odd, n_surv, n_fresh, ((uint64_t)sh.first_new_hi << 32) | sh.first_new_lo);
+    const uint64_t first_new = ((uint64_t)uniform(sh.first_new_hi) << 32) | uniform(sh.first_new_lo);
+    if (tracing) start_rays(args, odd, n_fresh, first_new);
+    else start_paths<COUNT>(args, odd, n_surv, n_fresh, first_new);
     if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
-    __syncthreads();  // the new rays are visible to the whole block
+    wave_sync();  // the new rays are visible to every lane
     if (LDS_SCENE && small_scene) scan_rays<COUNT>(args, lds_address, odd, total, &work, &segments);
     else walk_rays<COUNT, LDS_SCENE>(args, lds_address, odd, total, &work, &segments);
-    __syncthreads();  // every walked ray's record, surface hit included, sits in one of the region's queues
+    wave_sync();  // every walked ray's record, surface hit included, sits in one of the region's queues
     if (COUNT) ts = clock64();
     if (tracing) report_hits<LDS_SCENE>(args, lds_address, odd);
     else shade_queues<COUNT, LDS_SCENE>(args, lds_address, odd);
     if (COUNT) work.cycles[MIRT_PHASE_SHADE] += clock64() - ts;
-    __syncthreads();
-    n_surv = sh.n_next;
-    __syncthreads();  // everyone has read the counters thread 0 is about to reset
+    wave_sync();
+    n_surv = uniform(sh.n_next);
   }
 
   WorkCounters* const work_out = pinned(args)->work;
-  if (threadIdx.x == 0) atomicMax(&work_out->rounds, rounds);
+  if (lane_id() == 0) atomicMax(&work_out->rounds, rounds);
   if (COUNT) {
     work.cycles[MIRT_PHASE_TOTAL] = clock64() - k_begin;
     // one atomic per wave; a lane's phase clocks stop when it leaves a loop early, so the wave's time is the max
@@ -1871,7 +1885,7 @@ hipError_t static_workspace_address(int device, void** out) {
 RenderConfig plan_render(const DeviceScene& sc) {
   RenderConfig cfg{};
   cfg.block = RENDER_THREADS;
-  cfg.grid = N_REGIONS;
+  cfg.grid = RENDER_BLOCKS;
   // a stack entry per inner node on the path plus the pending sibling of the last one
   const int depth = (int)sc.bvh_height + 2;
   // nodes, 48-byte primitive records, wrapper chains; then what shading looks up: materials, textures, lights
@@ -1919,7 +1933,7 @@ static hipError_t launch_render_as(const RenderArgs* args, const RenderConfig& c
     if (e != hipSuccess) return e;
     if (device < 64) devices_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_render<COUNT, LDS_SCENE>), dim3(cfg.grid), dim3(RENDER_THREADS), cfg.lds_bytes, stream, args);
+  hipLaunchKernelGGL((k_render<COUNT, LDS_SCENE>), dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, stream, args);
   return hipGetLastError();
 }
 

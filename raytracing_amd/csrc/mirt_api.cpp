@@ -814,7 +814,7 @@ struct Workspace {
   RenderState* state;
   WorkCounters* work;
   RenderArgs* args;
-  uint4* saves;       // walks put aside: 2 * N_REGIONS * save_cap entries of SAVE_QUADS quads
+  uint4* saves;       // walks put aside: 2 * regions * save_cap entries of SAVE_QUADS quads
   uint32_t save_cap;
 };
 
@@ -842,13 +842,17 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   if (job.fixed_workspace && job.want_pool > STATIC_POOL_PATHS)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "path_pool beyond the " + std::to_string(STATIC_POOL_PATHS) +
                                                     " paths the fixed workspace holds");
-  // paths in flight: a whole number of waves per region, no more than the job has paths
+  RenderConfig cfg = plan_render(scene->view);
+  if (job.fixed_workspace) cfg.block = (int)STATIC_WAVES_PER_BLOCK * 64;  // fewer waves, so a region still holds a wave's worth
+  const uint32_t regions = cfg.regions();
+  // paths in flight: every wave's region a whole number of 64 slots, no more than the job has paths
+  const uint32_t granule = regions * 64u;
   uint64_t want = job.want_pool ? job.want_pool : (job.fixed_workspace ? STATIC_POOL_PATHS : (1u << 23));
   want = std::min<uint64_t>(want, total);
-  want = std::min<uint64_t>(std::max<uint64_t>(want, POOL_GRANULE), 1u << 27);
-  const uint32_t pool = (uint32_t)((want + POOL_GRANULE - 1) / POOL_GRANULE * POOL_GRANULE);
+  want = std::min<uint64_t>(std::max<uint64_t>(want, granule), 1u << 27);
+  const uint32_t pool = (uint32_t)((want + granule - 1) / granule * granule);
   job.rc.pool = pool;
-  job.rc.region_cap = pool / N_REGIONS;
+  job.rc.region_cap = pool / regions;
 
   Workspace ws;
   if (job.fixed_workspace) {
@@ -863,7 +867,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
     MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
     MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
     const uint32_t save_cap = std::max(64u, job.rc.region_cap / 4);
-    MIRT_HIP(ctx, ctx->saves.ensure((size_t)2 * N_REGIONS * save_cap * SAVE_QUADS * 16));
+    MIRT_HIP(ctx, ctx->saves.ensure((size_t)2 * regions * save_cap * SAVE_QUADS * 16));
     ws = Workspace{{ctx->paths[0].as<float4>(), ctx->paths[1].as<float4>()}, ctx->queues.as<float4>(),
                    ctx->state.as<RenderState>(), ctx->work.as<WorkCounters>(), ctx->args.as<RenderArgs>(),
                    ctx->saves.as<uint4>(), save_cap};
@@ -874,7 +878,6 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
 
   const bool count_work = (job.flags & MIRT_RENDER_COUNT_WORK) != 0;
   const bool time_kernels = (job.flags & MIRT_RENDER_TIME_KERNELS) != 0 && !job.fixed_workspace;
-  const RenderConfig cfg = plan_render(scene->view);
   if (std::getenv("MIRT_VERBOSE"))
     std::fprintf(stderr, "mirt: %zu prims, %u nodes, height %u; %s, %d x %d threads, %zu B LDS, stack %d; pool %u\n",
                  scene->n_prims, scene->view.n_nodes, scene->view.bvh_height,
@@ -902,6 +905,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.work = ws.work;
   args.rgb_sum = job.rgb_sum;
   args.refill_min = cfg.refill_min;
+  args.waves_per_block = (uint32_t)cfg.block / 64u;
   // Large scenes (from 2^18 primitives): a ray takes at most `budget` steps per round; longer walks are put aside
   // and go on in the next round, so the few rays that graze such a scene for thousands of steps no longer hold up
   // every round.  Smaller scenes have no such rays and would only pay for the bookkeeping.
@@ -911,7 +915,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
     // (a very unbalanced tree: the deep end of the stacks lives in global memory)
     if (job.fixed_workspace) return fail(ctx, MIRT_ERR_UNSUPPORTED, "this scene's tree needs stack rows the fixed workspace does not hold");
     args.overflow_levels = 3 * scene->view.bvh_height + 1 - (uint32_t)WIDE_LDS_STACK;
-    MIRT_HIP(ctx, ctx->overflow.ensure((size_t)N_REGIONS * args.overflow_levels * RENDER_THREADS * 4));
+    MIRT_HIP(ctx, ctx->overflow.ensure((size_t)cfg.grid * args.overflow_levels * RENDER_THREADS * 4));
     args.stack_overflow = ctx->overflow.as<uint32_t>();
   }
   args.step_budget = 0;

@@ -40,7 +40,8 @@ constexpr int STACK_DEPTH = 32;
 constexpr int WIDE_LDS_STACK = 38;
 constexpr int WIDE_MAX_STACK = 3 * (STACK_DEPTH - 2) + 1;
 constexpr uint32_t SAVE_STACK = 40;
-constexpr int RENDER_THREADS = 1024;    // render: one block per region, a CU's worth of waves
+constexpr int RENDER_THREADS = 1024;    // render: one block per CU, a CU's worth of waves (the most a block may have)
+constexpr int RENDER_BLOCKS = 256;
 constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 
 // BVH node, 64 bytes = 4 x float4:
@@ -143,11 +144,10 @@ struct DeviceScene {
 };
 
 // ---- the path pool ----------------------------------------------------------------
-// The pool is split into N_REGIONS equal regions of consecutive slots, one per block of the render kernel.
-// A region is private to its block: two buffers of path records (this round's and the next one's) and N_QUEUES
-// shading queues of path records.  The only thing the blocks share is the counter new paths are numbered from.
-constexpr uint32_t N_REGIONS = 256;
-constexpr uint32_t POOL_GRANULE = N_REGIONS * 64;  // a region is a whole number of waves
+// The pool is split into equal regions of consecutive slots, one per wave of the render kernel (RenderConfig::regions).
+// A region is private to its wave: two buffers of path records (this round's and the next one's) and N_QUEUES
+// shading queues of path records.  The only thing the waves share is the counter new paths are numbered from.
+constexpr uint32_t N_REGIONS = RENDER_BLOCKS * (RENDER_THREADS / 64);  // of a launch with full blocks
 
 struct RenderState {
   unsigned long long issued;  // camera paths handed out so far (may run past the render's total)
@@ -231,23 +231,27 @@ constexpr uint32_t MAX_DEPTH_LIMIT = 255;
 // For callers that may not allocate device memory: a file-scope device array in kernels.hip, one copy per GPU,
 // holding a path pool of STATIC_POOL_PATHS records (two record buffers and N_QUEUES queues: 640 bytes a path)
 // behind a control page with the render's counters and launch arguments.
+// The render kernel runs there with four waves to a block, each with a region of 64 paths.
 constexpr uint32_t STATIC_POOL_PATHS = 65536;
-constexpr uint32_t STATIC_SAVE_CAP = 32;  // walks put aside per region and round in the fixed workspace
+constexpr uint32_t STATIC_WAVES_PER_BLOCK = 4;
+constexpr uint32_t STATIC_REGIONS = RENDER_BLOCKS * STATIC_WAVES_PER_BLOCK;
+constexpr uint32_t STATIC_SAVE_CAP = 16;  // walks put aside per region and round in the fixed workspace
 constexpr size_t STATIC_CONTROL_BYTES = 4096;
-constexpr size_t STATIC_SAVE_BYTES = (size_t)N_REGIONS * 2 * STATIC_SAVE_CAP * 16 * (2 + 40 / 4);
+constexpr size_t STATIC_SAVE_BYTES = (size_t)STATIC_REGIONS * 2 * STATIC_SAVE_CAP * 16 * (2 + 40 / 4);
 constexpr size_t STATIC_WORKSPACE_BYTES =
     STATIC_CONTROL_BYTES + (size_t)STATIC_POOL_PATHS * 64 * (2 + N_QUEUES) + STATIC_SAVE_BYTES;
 // Address of the current device's copy (`device` must be the current device); looked up once per device.
 hipError_t static_workspace_address(int device, void** out);
 
 // ---- launchers implemented in kernels.hip ------------------------------------
-// How the render kernel is launched for a scene: one 1024-thread block per region, with nodes, primitive
+// How the render kernel is launched for a scene: one block per CU, one region per wave, with nodes, primitive
 // records, wrapper chains, materials, textures and the light list staged in LDS when they fit beside the block's
 // traversal stacks, else read from global memory.
 struct RenderConfig {
   bool lds_scene;
-  int block;
+  int block;  // threads per block: a multiple of 64, at most RENDER_THREADS
   int grid;
+  uint32_t regions() const { return (uint32_t)grid * ((uint32_t)block / 64u); }
   int stack_depth;
   size_t lds_bytes;
   uint32_t refill_min;  // a wave hands in finished rays and fetches new ones once this many lanes have none
@@ -265,6 +269,7 @@ struct RenderArgs {
   WorkCounters* work;
   float* rgb_sum;
   uint32_t refill_min, node_min;
+  uint32_t waves_per_block;  // block size of the launch / 64; wave w of block b owns region b * waves_per_block + w
   // Scenes walked from global memory: a ray takes at most this many steps (tree steps + primitive tests) per
   // round; then its walk is put aside in `saves` (save_cap entries of SAVE_QUADS quads per region and round
   // parity) and goes on in the next round, so that the few rays that graze a large scene for thousands of steps do
