@@ -961,12 +961,10 @@ constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 struct WaveShared {
   uint32_t n_fresh;                     // camera paths started this round, in the slots after the survivors
   uint32_t first_new_lo, first_new_hi;  // number of the first of them among the render's paths
-  uint32_t next_work;                   // next slot to hand out to the walk
   uint32_t queue_n[N_QUEUES];           // entries in the region's material queues
   uint32_t n_next;                      // survivors written to the other buffer so far
   uint32_t late_n[N_QUEUES];            // entries appended to each queue for the second shading pass
-  uint32_t n_saved;                     // walks put aside this round (entries of the region's save area in use)
-  uint32_t pad[10];
+  uint32_t pad[12];
 };
 static_assert(sizeof(WaveShared) == 128, "one LDS row half per wave");
 struct RenderShared {
@@ -1182,36 +1180,64 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   uint32_t slot = NO_SLOT;  // slot of the ray this lane is walking
   float4 state = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // what the record holds besides the ray: throughput, sample | bounce
   float pixel_bits = 0.0f;
-  bool more = true;         // rays left to hand out, as far as this wave knows
-  // Every turn of this loop the wave first hands in finished rays and fetches new ones if enough lanes
-  // are without work, then steps down the tree until (almost) every lane holds a leaf, then tests one
-  // primitive in every lane that holds a leaf.
+  bool more = true;         // rays left to hand out
+  // The region is this wave's alone, so its counters are registers: lane k counts the entries of queue k,
+  // the rest is the same number in every lane.
+  uint32_t queue_fill = 0;
+  uint32_t n_saved = 0;     // walks put aside this round (entries of the region's save area in use)
+  uint32_t next_entry = 0;  // next slot to hand out
+  // Scenes in LDS: the walk waits for nothing but the rays themselves, so those are read ahead of their use.
+  // Lane l of `ahead` holds slot next_entry + l, loaded right after the last exchange (the loads are in flight
+  // while the wave walks); a lane that needs a ray takes it from the lane that holds it (a register exchange, no
+  // memory), and the 64 slots after the ones handed out are loaded for the next exchange.
+  // (Every lane loads, past the end of the list the last slot again, and after every exchange whether or not
+  // the buffer was used up: a load under a condition would have to be merged with the registers' old contents,
+  // and that merge would wait for it on the spot.)
+  constexpr bool AHEAD = LDS_SCENE;
+  float4 ahead[3];
+  for (int k = 0; k < 3; ++k) ahead[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  auto read_ahead = [&](uint32_t first) {
+    const uint32_t e = min(first + lane, total - 1u);
+    ahead[0] = cur[4 * (size_t)e]; ahead[1] = cur[4 * (size_t)e + 1]; ahead[2] = cur[4 * (size_t)e + 2];
+  };
+  if (AHEAD) read_ahead(0u);
+  auto from_lane = [](const float4& v, uint32_t byte_address) {
+    return make_float4(__int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_address, __float_as_int(v.x))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_address, __float_as_int(v.y))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_address, __float_as_int(v.z))),
+                       __int_as_float(__builtin_amdgcn_ds_bpermute((int)byte_address, __float_as_int(v.w))));
+  };
+  // The wave alternates between two things.  Exchange: rays that are done are handed in and the lanes without
+  // work get new rays.  Walk: step down the tree until (almost) every lane holds a leaf, then one primitive test in
+  // every lane that holds a leaf, and so on until enough lanes are without work for another exchange.
+  // done: the closest hit is known (finished), or the round's budget is used up and the walk is put aside (spent).
+  bool finished = false, spent = false;
   for (;;) {
-    // done: the closest hit is known.  spent: the round's budget is used up and the walk is put aside.
-    const bool finished = slot != NO_SLOT && w.cur == RC::NONE;
-    const bool spent = !LDS_SCENE && step_budget != 0u && slot != NO_SLOT && !finished && w.steps >= step_budget &&
-                       w.sp <= SAVE_STACK;  // (a stack deeper than a save entry holds walks on)
-    const bool done = finished || spent;
-    const unsigned long long m_done = __ballot(done);
-    const unsigned long long m_out = m_done | __ballot(slot == NO_SLOT);
-    const uint32_t n_out = (uint32_t)__popcll(m_out);
-    if (n_out == 64u && m_done == 0ull && !more) break;
-    if ((m_done != 0ull || more) && (n_out >= refill_min || n_out == 64u)) {
+    {
+      const bool done = finished || spent;
       if (COUNT) ts = clock64();
+      const uint32_t base = next_entry;
+      float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+      // the lanes that will be without work after the hand-in (a spent walk stays when the save area is full:
+      // its lane is then passed over although it was counted, and gets no ray either)
+      const unsigned long long m_spent = LDS_SCENE ? 0ull : __ballot(spent);
+      const unsigned long long m_free = __ballot(done) | __ballot(slot == NO_SLOT);
+      const uint32_t n_free = (uint32_t)__popcll(m_free);
+      const uint32_t rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
+      if (AHEAD && more) {
+        // the rays the free lanes will take, out of the lanes that hold them, and the loads for the next exchange
+        r0 = from_lane(ahead[0], rank << 2);
+        r1 = from_lane(ahead[1], rank << 2);
+        r2 = from_lane(ahead[2], rank << 2);
+        read_ahead(base + n_free);
+      }
       // Rays that are done leave their hit in the record and their slot in the queue of the material
-      // hit.  Lane q reserves queue q's entries for the whole wave in the block's LDS counters; the lane after
-      // those takes the wave's new rays off the region's list.
+      // hit.  Lane q keeps the fill of queue q and reserves its entries for the whole wave.
       int q = !done ? -1 : (w.best_ref == REF_NONE ? QUEUE_MISS : queue_of(w.best_material));
       if (q == QUEUE_LAMBERTIAN && ref_tag(w.best_ref) >= TAG_RECT) q = QUEUE_LAMBERTIAN_FLAT;
       uint32_t saved_at = 0;  // 1 + entry of the save area
       if (!LDS_SCENE && spent) {
-        // (one LDS atomic per wave; a full save area leaves the ray walking)
-        const unsigned long long m_spent = __ballot(1);
-        const uint32_t leader = (uint32_t)__ffsll((long long)m_spent) - 1u;
-        uint32_t first = 0;
-        if (lane == leader) first = atomicAdd(&sh.n_saved, (uint32_t)__popcll(m_spent));
-        first = __shfl(first, leader);
-        const uint32_t at = first + (uint32_t)__popcll(m_spent & ((1ull << lane) - 1ull));
+        const uint32_t at = n_saved + (uint32_t)__popcll(m_spent & ((1ull << lane) - 1ull));
         if (at < save_cap) {
           saved_at = at + 1u;
           q = QUEUE_CONTINUE;
@@ -1226,10 +1252,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
           w.steps = 0;  // walks another budget's worth before it asks again
         }
       }
-      // the lanes that really leave (a spent walk stays when the save area is full) and the lanes to refill
+      if (!LDS_SCENE) n_saved += (uint32_t)__popcll(m_spent);
       const bool leaving = q >= 0;
-      const unsigned long long m_free = __ballot(leaving) | __ballot(slot == NO_SLOT);
-      const uint32_t n_free = (uint32_t)__popcll(m_free);
       unsigned long long mq = 0ull;  // the lanes handing in to the same queue as this one
       uint32_t cnt = 0;
 #pragma unroll
@@ -1238,14 +1262,9 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         if (q == k) mq = m;
         if (lane == (uint32_t)k) cnt = (uint32_t)__popcll(m);
       }
-      uint32_t got = 0;
-      if (lane < (uint32_t)N_QUEUES) {
-        if (cnt) got = atomicAdd(&sh.queue_n[lane], cnt);
-      } else if (lane == (uint32_t)N_QUEUES && more) {
-        got = atomicAdd(&sh.next_work, n_free);
-      }
-      const uint32_t base = __builtin_amdgcn_readlane(got, N_QUEUES);
-      const uint32_t bq = __shfl(got, q < 0 ? 0 : q);  // every lane takes part: the reserving lanes may not be done
+      const uint32_t got = queue_fill;
+      queue_fill += cnt;
+      const uint32_t bq = __shfl(got, q < 0 ? 0 : q);  // every lane takes part: the lanes that keep the fills may not be done
       if (leaving) {
         const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
         // the whole path record moves into the queue, hit included: shading reads its queue front to back
@@ -1263,11 +1282,12 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       // the tree together)
       if (more) {
         more = base + n_free < total;
-        const uint32_t entry = base + (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
+        next_entry = base + n_free;
+        const uint32_t entry = base + rank;
         if (slot == NO_SLOT && entry < total) {
           slot = entry;
-          const float4 r0 = cur[4 * (size_t)slot], r1 = cur[4 * (size_t)slot + 1];
-          state = cur[4 * (size_t)slot + 2];
+          if (!AHEAD) { r0 = cur[4 * (size_t)slot]; r1 = cur[4 * (size_t)slot + 1]; r2 = cur[4 * (size_t)slot + 2]; }
+          state = r2;
           pixel_bits = r1.w;
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
@@ -1292,23 +1312,36 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       }
       if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
     }
-    if (COUNT) ts = clock64();
-    while (!(w.cur & RC::LEAF)) {
-      if (COUNT) { ++work.nodes; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_nodes; }
-      if constexpr (LDS_SCENE) node_step<true>(w, tb, kTMin, st);
-      else wide_step(w, tb, kTMin, st);
-      if (!LDS_SCENE) ++w.steps;
-      // the last few lanes still on their way down do not keep the others waiting
-      if ((uint32_t)__popcll(__ballot(!(w.cur & RC::LEAF))) < node_min) break;
+    bool all_out = false;
+    for (;;) {
+      if (COUNT) ts = clock64();
+      while (!(w.cur & RC::LEAF)) {
+        if (COUNT) { ++work.nodes; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_nodes; }
+        if constexpr (LDS_SCENE) node_step<true>(w, tb, kTMin, st);
+        else wide_step(w, tb, kTMin, st);
+        if (!LDS_SCENE) ++w.steps;
+        // the last few lanes still on their way down do not keep the others waiting
+        if ((uint32_t)__popcll(__ballot(!(w.cur & RC::LEAF))) < node_min) break;
+      }
+      if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_NODES] += now - ts; ts = now; }
+      if ((w.cur & RC::LEAF) && w.cur != RC::NONE) {
+        if (COUNT) { ++work.prims; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_prims; }
+        prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, st);
+        if (!LDS_SCENE) ++w.steps;
+      }
+      if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - ts;
+      finished = slot != NO_SLOT && w.cur == RC::NONE;
+      spent = !LDS_SCENE && step_budget != 0u && slot != NO_SLOT && !finished && w.steps >= step_budget &&
+              w.sp <= SAVE_STACK;  // (a stack deeper than a save entry holds walks on)
+      const unsigned long long m_done = __ballot(finished || spent);
+      const uint32_t n_out = (uint32_t)__popcll(m_done | __ballot(slot == NO_SLOT));
+      all_out = n_out == 64u && m_done == 0ull && !more;
+      if (all_out) break;
+      if ((m_done != 0ull || more) && (n_out >= refill_min || n_out == 64u)) break;
     }
-    if (COUNT) { const long long now = clock64(); work.cycles[MIRT_PHASE_NODES] += now - ts; ts = now; }
-    if ((w.cur & RC::LEAF) && w.cur != RC::NONE) {
-      if (COUNT) { ++work.prims; if (lane == (uint32_t)__ffsll((long long)__ballot(1)) - 1u) ++work.wave_prims; }
-      prim_step<PSTRIDE, LDS_SCENE>(w, tb, kTMin, st);
-      if (!LDS_SCENE) ++w.steps;
-    }
-    if (COUNT) work.cycles[MIRT_PHASE_PRIMS] += clock64() - ts;
+    if (all_out) break;
   }
+  if (lane < (uint32_t)N_QUEUES) sh.queue_n[lane] = queue_fill;  // for shading
   if (COUNT) {
     work_out->nodes += work.nodes; work_out->prims += work.prims;
     work_out->wave_nodes += work.wave_nodes; work_out->wave_prims += work.wave_prims;
@@ -1340,11 +1373,8 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
   uint32_t segments = 0;
   long long ts = 0;
   Work work{};
-  for (;;) {
+  for (uint32_t base = 0;; base += 64u) {
     if (COUNT) ts = clock64();
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&sh.next_work, 64u);
-    base = uniform(base);
     if (base >= total) break;
     const uint32_t entry = base + lane;
     const bool live = entry < total;
@@ -1761,10 +1791,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
         sh.first_new_hi = (uint32_t)(first >> 32);
       }
       sh.n_fresh = fresh;
-      sh.next_work = 0;
       for (int q = 0; q < N_QUEUES; ++q) { sh.queue_n[q] = 0; sh.late_n[q] = 0; }
       sh.n_next = 0;
-      sh.n_saved = 0;
     }
     wave_sync();
     const uint32_t n_fresh = uniform(sh.n_fresh);
