@@ -1061,7 +1061,8 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
   const uint32_t width = A->rc.width, height = A->rc.height, first_sample = A->rc.first_sample;
   const uint32_t key0 = A->rc.key0, key1 = A->rc.key1;
   const uint32_t n_groups = A->rc.n_groups, group_stride = A->rc.group_stride;
-  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * A->rc.region_cap;
+  const size_t cap = A->rc.region_cap;
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
   const V3 cu = v3(A->rc.cam.u[0], A->rc.cam.u[1], A->rc.cam.u[2]);
   const V3 cv = v3(A->rc.cam.v[0], A->rc.cam.v[1], A->rc.cam.v[2]);
   const V3 origin = v3(A->rc.cam.origin[0], A->rc.cam.origin[1], A->rc.cam.origin[2]);
@@ -1127,10 +1128,10 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
     const V3 offset = cu * rd.x + cv * rd.y;
     const V3 d = llc + u * hor + v * ver - origin - offset;
     const V3 o = origin + offset;
-    cur[4 * i] = make_float4(o.x, o.y, o.z, time);
-    cur[4 * i + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
-    cur[4 * i + 2] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
-    if (budgeted) cur[4 * i + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // no walk put aside: starts at the root
+    cur[i] = make_float4(o.x, o.y, o.z, time);
+    cur[cap + i] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
+    cur[2 * cap + i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
+    if (budgeted) cur[3 * cap + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // no walk put aside: starts at the root
   }
 }
 
@@ -1198,7 +1199,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   for (int k = 0; k < 3; ++k) ahead[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   auto read_ahead = [&](uint32_t first) {
     const uint32_t e = min(first + lane, total - 1u);
-    ahead[0] = cur[4 * (size_t)e]; ahead[1] = cur[4 * (size_t)e + 1]; ahead[2] = cur[4 * (size_t)e + 2];
+    ahead[0] = cur[e]; ahead[1] = cur[(size_t)cap + e]; ahead[2] = cur[2 * (size_t)cap + e];
   };
   if (AHEAD) read_ahead(0u);
   auto from_lane = [](const float4& v, uint32_t byte_address) {
@@ -1268,11 +1269,11 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       if (leaving) {
         const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
         // the whole path record moves into the queue, hit included: shading reads its queue front to back
-        float4* const out = region_queues + 4 * ((size_t)q * cap + pos);
+        float4* const out = region_queues + 4 * (size_t)q * cap + pos;
         out[0] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, w.r.time);
-        out[1] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, pixel_bits);
-        out[2] = state;
-        out[3] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), __uint_as_float(saved_at));
+        out[cap] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, pixel_bits);
+        out[2 * (size_t)cap] = state;
+        out[3 * (size_t)cap] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), __uint_as_float(saved_at));
         slot = NO_SLOT;
         w.cur = RC::NONE;
         if (LDS_SCENE || q != QUEUE_CONTINUE) ++segments;
@@ -1286,14 +1287,14 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         const uint32_t entry = base + rank;
         if (slot == NO_SLOT && entry < total) {
           slot = entry;
-          if (!AHEAD) { r0 = cur[4 * (size_t)slot]; r1 = cur[4 * (size_t)slot + 1]; r2 = cur[4 * (size_t)slot + 2]; }
+          if (!AHEAD) { r0 = cur[slot]; r1 = cur[(size_t)cap + slot]; r2 = cur[2 * (size_t)cap + slot]; }
           state = r2;
           pixel_bits = r1.w;
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
           walk_begin(w, r, root, time_slice_base(r.time, n_slices, slice_time0, slice_scale, n_nodes));
           if (!LDS_SCENE && step_budget != 0u) {
-            const uint32_t saved_in = __float_as_uint(cur[4 * (size_t)slot + 3].x);
+            const uint32_t saved_in = __float_as_uint(cur[3 * (size_t)cap + slot].x);
             if (saved_in != 0u) {  // a walk put aside in the last round: on from where it stopped
               const uint4* const sv = saves_in + (size_t)SAVE_QUADS * (saved_in - 1u);
               const uint4 a = sv[0], b = sv[1];
@@ -1379,7 +1380,7 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
     const uint32_t entry = base + lane;
     const bool live = entry < total;
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, state = r0;
-    if (live) { r0 = cur[4 * (size_t)entry]; r1 = cur[4 * (size_t)entry + 1]; state = cur[4 * (size_t)entry + 2]; }
+    if (live) { r0 = cur[entry]; r1 = cur[(size_t)cap + entry]; state = cur[2 * (size_t)cap + entry]; }
     Ray r;
     r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
     float best_t = kInf;
@@ -1415,11 +1416,11 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
     const uint32_t bq = __shfl(got, q < 0 ? 0 : q);
     if (live) {
       const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
-      float4* const out = region_queues + 4 * ((size_t)q * cap + pos);
+      float4* const out = region_queues + 4 * (size_t)q * cap + pos;
       out[0] = r0;
-      out[1] = r1;
-      out[2] = state;
-      out[3] = make_float4(best_t, __uint_as_float(best_ref), __uint_as_float(best_face), 0.0f);
+      out[cap] = r1;
+      out[2 * (size_t)cap] = state;
+      out[3 * (size_t)cap] = make_float4(best_t, __uint_as_float(best_ref), __uint_as_float(best_face), 0.0f);
       ++segments;
     }
     if (COUNT) work.cycles[MIRT_PHASE_WRITE] += clock64() - ts;
@@ -1487,7 +1488,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
 #pragma unroll
       for (int k = 1; k < N_QUEUES; ++k)
         if (batch >= last_batch[k - 1]) { q = k; n_q = count[k]; e0 = (batch - last_batch[k - 1]) << 6; from = first[k]; }
-      float4* const entries = region_queues + 4 * ((size_t)q * cap + from);
+      float4* const entries = region_queues + 4 * (size_t)q * cap + from;
       const uint32_t e = e0 + lane;
       bool alive = false;
       Ray nr;
@@ -1495,8 +1496,8 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       uint32_t pixel = 0, sample = 0, bounce = 0;
       uint32_t saved_walk = 0;  // 1 + entry of the save area for a ray whose walk was put aside
       if (e < n_q) {
-        const float4* const rec = entries + 4 * (size_t)e;
-        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        const float4* const rec = entries + e;
+        const float4 r0 = rec[0], r1 = rec[cap], r2 = rec[2 * (size_t)cap], r3 = rec[3 * (size_t)cap];
         Ray r;
         r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
         pixel = __float_as_uint(r1.w);
@@ -1517,9 +1518,9 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
             if (to_q != q) {  // another material's code: goes to the end of that queue, for the second pass
               deferred = true;
               const uint32_t at = sh.queue_n[to_q] + atomicAdd(&sh.late_n[to_q], 1u);
-              float4* const out = region_queues + 4 * ((size_t)to_q * cap + at);
-              out[0] = r0; out[1] = r1; out[2] = r2;
-              out[3] = make_float4(t, __uint_as_float(ref), r3.z, r3.w);
+              float4* const out = region_queues + 4 * (size_t)to_q * cap + at;
+              out[0] = r0; out[cap] = r1; out[2 * (size_t)cap] = r2;
+              out[3 * (size_t)cap] = make_float4(t, __uint_as_float(ref), r3.z, r3.w);
             }
           }
         }
@@ -1601,10 +1602,10 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       // survivors are packed into the first slots of the region's other buffer
       const size_t to = wave_reserve(alive, &sh.n_next);
       if (alive) {
-        next[4 * to] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
-        next[4 * to + 1] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
-        next[4 * to + 2] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
-        if (budgeted) next[4 * to + 3] = make_float4(__uint_as_float(saved_walk), 0.0f, 0.0f, 0.0f);
+        next[to] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
+        next[cap + to] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
+        next[2 * (size_t)cap + to] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
+        if (budgeted) next[3 * (size_t)cap + to] = make_float4(__uint_as_float(saved_walk), 0.0f, 0.0f, 0.0f);
       }
     }
     if (n_media == 0 || pass == 1u) break;
@@ -1619,14 +1620,15 @@ __device__ __noinline__ void start_rays(const RenderArgs* args, bool odd, uint32
   odd = uniform(odd) != 0;
   n_fresh = uniform(n_fresh);
   first_new = ((uint64_t)uniform((uint32_t)(first_new >> 32)) << 32) | uniform((uint32_t)first_new);
-  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region_of_wave(A) * A->rc.region_cap;
+  const size_t cap = A->rc.region_cap;
+  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region_of_wave(A) * cap;
   const mirt_ray* const rays = A->rays;
   for (uint32_t k = lane_id(); k < n_fresh; k += 64u) {
     const uint64_t g = first_new + k;
     const mirt_ray in = rays[g];
-    cur[4 * (size_t)k] = make_float4(in.origin[0], in.origin[1], in.origin[2], in.time);
-    cur[4 * (size_t)k + 1] = make_float4(in.direction[0], in.direction[1], in.direction[2], __uint_as_float((uint32_t)g));
-    cur[4 * (size_t)k + 2] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    cur[k] = make_float4(in.origin[0], in.origin[1], in.origin[2], in.time);
+    cur[cap + k] = make_float4(in.direction[0], in.direction[1], in.direction[2], __uint_as_float((uint32_t)g));
+    cur[2 * cap + k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
   }
 }
 
@@ -1662,8 +1664,8 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
     const uint32_t n_q = uniform(sh.queue_n[q]);
     const float4* entries = region_queues + 4 * (size_t)q * cap;
     for (uint32_t e = lane_id(); e < n_q; e += 64u) {
-      const float4* const rec = entries + 4 * (size_t)e;
-      const float4 r0 = rec[0], r1 = rec[1], r3 = rec[3];
+      const float4* const rec = entries + e;
+      const float4 r0 = rec[0], r1 = rec[cap], r3 = rec[3 * (size_t)cap];
       Ray r;
       r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
       const uint32_t g = __float_as_uint(r1.w);
