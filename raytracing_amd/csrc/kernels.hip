@@ -1048,43 +1048,27 @@ struct RenderLds {
 // The three phases of a round are separate functions so that each gets registers of its own: the walk needs
 // few and must not spill, shading needs many.
 
-// Starts n_fresh camera paths (renderer.rs:215-218, camera.rs:57-68) in the region's slots after the survivors.
-template <bool COUNT>
-__device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint32_t n_surv, uint32_t n_fresh,
-                                         uint64_t first_new) {
-  ConstArgs A = pinned(args);
-  odd = uniform(odd) != 0;
-  n_surv = uniform(n_surv);
-  n_fresh = uniform(n_fresh);
-  first_new = ((uint64_t)uniform((uint32_t)(first_new >> 32)) << 32) | uniform((uint32_t)first_new);
-  const uint32_t region = region_of_wave(A);
-  const uint32_t width = A->rc.width, height = A->rc.height, first_sample = A->rc.first_sample;
-  const uint32_t key0 = A->rc.key0, key1 = A->rc.key1;
-  const uint32_t n_groups = A->rc.n_groups, group_stride = A->rc.group_stride;
-  const size_t cap = A->rc.region_cap;
-  float4* const cur = (odd ? A->paths_b : A->paths_a) + 4 * (size_t)region * cap;
-  const V3 cu = v3(A->rc.cam.u[0], A->rc.cam.u[1], A->rc.cam.u[2]);
-  const V3 cv = v3(A->rc.cam.v[0], A->rc.cam.v[1], A->rc.cam.v[2]);
-  const V3 origin = v3(A->rc.cam.origin[0], A->rc.cam.origin[1], A->rc.cam.origin[2]);
-  const V3 llc = v3(A->rc.cam.lower_left_corner[0], A->rc.cam.lower_left_corner[1], A->rc.cam.lower_left_corner[2]);
-  const V3 hor = v3(A->rc.cam.horizontal[0], A->rc.cam.horizontal[1], A->rc.cam.horizontal[2]);
-  const V3 ver = v3(A->rc.cam.vertical[0], A->rc.cam.vertical[1], A->rc.cam.vertical[2]);
-  const float lens_radius = A->rc.cam.lens_radius, time0 = A->rc.cam.time0, time1 = A->rc.cam.time1;
-  // the rows this call renders (all of them unless the caller asked for a band), y counted upwards
-  const uint32_t band_y0 = A->rc.band_y0, band_rows = A->rc.band_rows;
-  const uint32_t pixels = width * band_rows;
-  const FastDiv by_pixels{A->rc.by_pixels.m, A->rc.by_pixels.sh1, A->rc.by_pixels.sh2};
-  const FastDiv by_groups{A->rc.by_groups.m, A->rc.by_groups.sh1, A->rc.by_groups.sh2};
-  const FastDiv by_band{A->rc.by_band.m, A->rc.by_band.sh1, A->rc.by_band.sh2};
-  const uint32_t strata = A->rc.strata;
-  const bool budgeted = A->step_budget != 0u;
-  const FastDiv by_strata{A->rc.by_strata.m, A->rc.by_strata.sh1, A->rc.by_strata.sh2};
-  const FastDiv by_cells{A->rc.by_cells.m, A->rc.by_cells.sh1, A->rc.by_cells.sh2};
-  // path number = pass * pixels + place in the pass; the one long division is done once for the block
-  const uint32_t first_pass = (uint32_t)(first_new / pixels);
-  const uint32_t first_place = (uint32_t)(first_new - (uint64_t)first_pass * pixels);
-  for (uint32_t k = lane_id(); k < n_fresh; k += 64u) {
-    const size_t i = n_surv + k;
+// Camera paths (renderer.rs:215-218, camera.rs:57-68).  A round's new paths are numbered first_new, first_new + 1, ...
+// among all paths of the render; path number = pass * pixels + place in the pass.
+struct CameraPaths {
+  ConstArgs A;
+  uint32_t first_pass, first_place;
+  __device__ __forceinline__ CameraPaths(ConstArgs args, uint64_t first_new) : A(args) {
+    const uint32_t pixels = A->rc.width * A->rc.band_rows;
+    // the one long division is done once for the round
+    first_pass = uniform((uint32_t)(first_new / pixels));
+    first_place = uniform((uint32_t)(first_new - (uint64_t)first_pass * pixels));
+  }
+  // The k-th of the round's new paths as the first three quads of a path record.
+  __device__ __forceinline__ void start(uint32_t k, float4& r0, float4& r1, float4& r2) const {
+    const uint32_t width = A->rc.width, height = A->rc.height;
+    // the rows this call renders (all of them unless the caller asked for a band), y counted upwards
+    const uint32_t band_rows = A->rc.band_rows;
+    const uint32_t pixels = width * band_rows;
+    const uint32_t n_groups = A->rc.n_groups;
+    const FastDiv by_pixels{A->rc.by_pixels.m, A->rc.by_pixels.sh1, A->rc.by_pixels.sh2};
+    const FastDiv by_groups{A->rc.by_groups.m, A->rc.by_groups.sh1, A->rc.by_groups.sh2};
+    const FastDiv by_band{A->rc.by_band.m, A->rc.by_band.sh1, A->rc.by_band.sh2};
     const uint32_t place = first_place + k;  // < 2^31 + 2^27
     const uint32_t more_passes = fast_div(place, by_pixels);
     const uint32_t pass = first_pass + more_passes;
@@ -1093,17 +1077,20 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
     // a sample of the whole frame and the regions cost about the same to trace.
     const uint32_t group = in_pass >> 6;
     if (group < n_groups) {
-      const uint32_t scaled = group * group_stride;
+      const uint32_t scaled = group * A->rc.group_stride;
       in_pass = ((scaled - fast_div(scaled, by_groups) * n_groups) << 6) | (in_pass & 63u);
     }
     uint32_t x, y;
     pixel_of(in_pass, width, band_rows, by_band, x, y);
-    y += band_y0;
+    y += A->rc.band_y0;
     const uint32_t pixel = y * width + x;
-    const uint32_t sample = first_sample + pass;
-    Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, key0, key1);
+    const uint32_t sample = A->rc.first_sample + pass;
+    Rng rng = rng_begin(pixel, sample, 0, STAGE_CAMERA, A->rc.key0, A->rc.key1);
     float jx = rng_next(rng), jy = rng_next(rng);
+    const uint32_t strata = A->rc.strata;
     if (strata != 0) {  // opt-in: sample k of a pixel stays inside cell k mod strata^2 of the pixel
+      const FastDiv by_strata{A->rc.by_strata.m, A->rc.by_strata.sh1, A->rc.by_strata.sh2};
+      const FastDiv by_cells{A->rc.by_cells.m, A->rc.by_cells.sh1, A->rc.by_cells.sh2};
       const uint32_t cell = sample - fast_div(sample, by_cells) * (strata * strata);
       const uint32_t cy = fast_div(cell, by_strata), cx = cell - cy * strata;
       jx = ((float)cx + jx) / (float)strata;
@@ -1114,7 +1101,8 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
     // The shutter time is drawn ahead of the lens sample (camera.rs:58,66 draws it after; the draws are
     // independent): a pinhole camera, whose lens sample is multiplied by zero, then needs neither the
     // rejection loop nor a second block of random numbers.
-    const float time = rng_range(rng, time0, time1);
+    const float time = rng_range(rng, A->rc.cam.time0, A->rc.cam.time1);
+    const float lens_radius = A->rc.cam.lens_radius;
     V3 disk = v3(0.0f, 0.0f, 0.0f);
     if (lens_radius != 0.0f) {
       for (;;) {  // vec3.rs:53-60
@@ -1124,23 +1112,30 @@ __device__ __noinline__ void start_paths(const RenderArgs* args, bool odd, uint3
         if (len2(disk) < 1.0f) break;
       }
     }
+    const V3 cu = v3(A->rc.cam.u[0], A->rc.cam.u[1], A->rc.cam.u[2]);
+    const V3 cv = v3(A->rc.cam.v[0], A->rc.cam.v[1], A->rc.cam.v[2]);
+    const V3 origin = v3(A->rc.cam.origin[0], A->rc.cam.origin[1], A->rc.cam.origin[2]);
+    const V3 llc = v3(A->rc.cam.lower_left_corner[0], A->rc.cam.lower_left_corner[1], A->rc.cam.lower_left_corner[2]);
+    const V3 hor = v3(A->rc.cam.horizontal[0], A->rc.cam.horizontal[1], A->rc.cam.horizontal[2]);
+    const V3 ver = v3(A->rc.cam.vertical[0], A->rc.cam.vertical[1], A->rc.cam.vertical[2]);
     const V3 rd = lens_radius * disk;
     const V3 offset = cu * rd.x + cv * rd.y;
     const V3 d = llc + u * hor + v * ver - origin - offset;
     const V3 o = origin + offset;
-    cur[i] = make_float4(o.x, o.y, o.z, time);
-    cur[cap + i] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
-    cur[2 * cap + i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
-    if (budgeted) cur[3 * cap + i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // no walk put aside: starts at the root
+    r0 = make_float4(o.x, o.y, o.z, time);
+    r1 = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
+    r2 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample << 8));
   }
-}
+};
 
-// Finds the closest surface of every live ray of the region (slots [0, total)) and puts each slot into the
-// queue of the material hit.  Lanes whose ray has finished pull the region's next ray instead of waiting for
-// the slowest lane of the wave.
+// Finds the closest surface of every live ray of the region and puts each one into the queue of the material
+// hit.  The region's rays are numbered [0, total): the first n_stored of them are path records in the region's
+// buffer (the survivors of the last round, or the caller's rays of a trace), the others are camera paths started
+// here, in registers, at the moment a lane takes one (they never exist in memory as rays).  Lanes whose ray has
+// finished pull the region's next ray instead of waiting for the slowest lane of the wave.
 template <bool COUNT, bool LDS_SCENE>
-__device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg, bool odd, uint32_t total, Work* work_out,
-                                       uint32_t* segments_out) {
+__device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg, bool odd, uint32_t n_stored, uint32_t total,
+                                       uint64_t first_new, Work* work_out, uint32_t* segments_out) {
   constexpr int THREADS = RENDER_THREADS;
   float4* const smem = lds_base(lds_arg);
   WaveShared& sh = reinterpret_cast<RenderShared*>(smem)->wave[wave_in_block()];
@@ -1149,6 +1144,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   ConstArgs A = pinned(args);
   odd = uniform(odd) != 0;
   total = uniform(total);
+  n_stored = uniform(n_stored);
+  const CameraPaths camera(A, ((uint64_t)uniform((uint32_t)(first_new >> 32)) << 32) | uniform((uint32_t)first_new));
   const RenderLds<LDS_SCENE> lds(smem, A);
   const SceneTables tb = lds.tables(A);
   // (the overflow rows of the block: [level][thread])
@@ -1191,14 +1188,14 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   // Lane l of `ahead` holds slot next_entry + l, loaded right after the last exchange (the loads are in flight
   // while the wave walks); a lane that needs a ray takes it from the lane that holds it (a register exchange, no
   // memory), and the 64 slots after the ones handed out are loaded for the next exchange.
-  // (Every lane loads, past the end of the list the last slot again, and after every exchange whether or not
+  // (Every lane loads, past the end of the stored rays the last one again, and after every exchange whether or not
   // the buffer was used up: a load under a condition would have to be merged with the registers' old contents,
   // and that merge would wait for it on the spot.)
   constexpr bool AHEAD = LDS_SCENE;
   float4 ahead[3];
   for (int k = 0; k < 3; ++k) ahead[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   auto read_ahead = [&](uint32_t first) {
-    const uint32_t e = min(first + lane, total - 1u);
+    const uint32_t e = min(first + lane, max(n_stored, 1u) - 1u);
     ahead[0] = cur[e]; ahead[1] = cur[(size_t)cap + e]; ahead[2] = cur[2 * (size_t)cap + e];
   };
   if (AHEAD) read_ahead(0u);
@@ -1225,7 +1222,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       const unsigned long long m_free = __ballot(done) | __ballot(slot == NO_SLOT);
       const uint32_t n_free = (uint32_t)__popcll(m_free);
       const uint32_t rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
-      if (AHEAD && more) {
+      if (AHEAD && more && base < n_stored) {
         // the rays the free lanes will take, out of the lanes that hold them, and the loads for the next exchange
         r0 = from_lane(ahead[0], rank << 2);
         r1 = from_lane(ahead[1], rank << 2);
@@ -1287,13 +1284,14 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         const uint32_t entry = base + rank;
         if (slot == NO_SLOT && entry < total) {
           slot = entry;
-          if (!AHEAD) { r0 = cur[slot]; r1 = cur[(size_t)cap + slot]; r2 = cur[2 * (size_t)cap + slot]; }
+          if (entry >= n_stored) camera.start(entry - n_stored, r0, r1, r2);
+          else if (!AHEAD) { r0 = cur[slot]; r1 = cur[(size_t)cap + slot]; r2 = cur[2 * (size_t)cap + slot]; }
           state = r2;
           pixel_bits = r1.w;
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
           walk_begin(w, r, root, time_slice_base(r.time, n_slices, slice_time0, slice_scale, n_nodes));
-          if (!LDS_SCENE && step_budget != 0u) {
+          if (!LDS_SCENE && step_budget != 0u && entry < n_stored) {
             const uint32_t saved_in = __float_as_uint(cur[3 * (size_t)cap + slot].x);
             if (saved_in != 0u) {  // a walk put aside in the last round: on from where it stopped
               const uint4* const sv = saves_in + (size_t)SAVE_QUADS * (saved_in - 1u);
@@ -1356,13 +1354,15 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
 // two kinds of primitive at once (with a tree over 8 primitives a ray tests 5 of them anyway, each lane another).
 // Closest hit, equal t to the higher order rank: the same answer as the tree walk.
 template <bool COUNT>
-__device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg, bool odd, uint32_t total, Work* work_out,
-                                       uint32_t* segments_out) {
+__device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg, bool odd, uint32_t n_stored, uint32_t total,
+                                       uint64_t first_new, Work* work_out, uint32_t* segments_out) {
   float4* const smem = lds_base(lds_arg);
   WaveShared& sh = reinterpret_cast<RenderShared*>(smem)->wave[wave_in_block()];
   ConstArgs A = pinned(args);
   odd = uniform(odd) != 0;
   total = uniform(total);
+  n_stored = uniform(n_stored);
+  const CameraPaths camera(A, ((uint64_t)uniform((uint32_t)(first_new >> 32)) << 32) | uniform((uint32_t)first_new));
   const RenderLds<true> lds(smem, A);
   const SceneTables tb = lds.tables(A);
   const uint32_t region = region_of_wave(A);
@@ -1380,7 +1380,10 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
     const uint32_t entry = base + lane;
     const bool live = entry < total;
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, state = r0;
-    if (live) { r0 = cur[entry]; r1 = cur[(size_t)cap + entry]; state = cur[2 * (size_t)cap + entry]; }
+    if (live) {
+      if (entry >= n_stored) camera.start(entry - n_stored, r0, r1, state);
+      else { r0 = cur[entry]; r1 = cur[(size_t)cap + entry]; state = cur[2 * (size_t)cap + entry]; }
+    }
     Ray r;
     r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
     float best_t = kInf;
@@ -1805,12 +1808,15 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
 
     if (COUNT) ts = clock64();
     const uint64_t first_new = ((uint64_t)uniform(sh.first_new_hi) << 32) | uniform(sh.first_new_lo);
-    if (tracing) start_rays(args, odd, n_fresh, first_new);
-    else start_paths<COUNT>(args, odd, n_surv, n_fresh, first_new);
+    // (a render's new paths are started by the walk itself; the rays of a trace come from the caller's array)
+    if (tracing) {
+      start_rays(args, odd, n_fresh, first_new);
+      wave_sync();  // the new rays are visible to every lane
+    }
     if (COUNT) work.cycles[MIRT_PHASE_LOAD] += clock64() - ts;
-    wave_sync();  // the new rays are visible to every lane
-    if (LDS_SCENE && small_scene) scan_rays<COUNT>(args, lds_address, odd, total, &work, &segments);
-    else walk_rays<COUNT, LDS_SCENE>(args, lds_address, odd, total, &work, &segments);
+    const uint32_t n_stored = tracing ? total : n_surv;
+    if (LDS_SCENE && small_scene) scan_rays<COUNT>(args, lds_address, odd, n_stored, total, first_new, &work, &segments);
+    else walk_rays<COUNT, LDS_SCENE>(args, lds_address, odd, n_stored, total, first_new, &work, &segments);
     wave_sync();  // every walked ray's record, surface hit included, sits in one of the region's queues
     if (COUNT) ts = clock64();
     if (tracing) report_hits<LDS_SCENE>(args, lds_address, odd);
