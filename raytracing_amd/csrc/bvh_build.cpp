@@ -158,8 +158,8 @@ struct Builder {
     }
     nd.left = l.ref;
     nd.right = r.ref;
-    nd.pad0 = 0;
-    nd.pad1 = 0;
+    nd.lgrow = 0.0f;
+    nd.rgrow = 0.0f;
     Child c;
     c.ref = node_index;
     c.box = l.box;
@@ -326,6 +326,33 @@ std::vector<QuantNode> quantize_wide(const WideBvh& wide) {
     }
   }
   return out;
+}
+
+namespace {
+// (the tree is no taller than the traversal stack, so the recursion is shallow)
+float growth_below(std::vector<HostNode>& nodes, uint32_t n_nodes, uint32_t n_copies, uint32_t ref,
+                   const std::vector<float>& prim_growth) {
+  if (ref == 0xFFFFFFFFu) return 0.0f;
+  if (ref & 0x80000000u) {
+    const uint32_t first = ref & 0x0FFFFFFFu, count = ((ref >> 28) & 7u) + 1u;
+    float g = 0.0f;
+    for (uint32_t k = first; k < first + count && k < prim_growth.size(); ++k) g = std::max(g, prim_growth[k]);
+    return g;
+  }
+  const float l = growth_below(nodes, n_nodes, n_copies, nodes[ref].left, prim_growth);
+  const float r = growth_below(nodes, n_nodes, n_copies, nodes[ref].right, prim_growth);
+  for (uint32_t c = 0; c < n_copies; ++c) {
+    nodes[(size_t)c * n_nodes + ref].lgrow = l;
+    nodes[(size_t)c * n_nodes + ref].rgrow = r;
+  }
+  return std::max(l, r);
+}
+}  // namespace
+
+void set_box_growth(std::vector<HostNode>& nodes, uint32_t n_nodes, uint32_t n_copies, uint32_t root_ref,
+                    const std::vector<float>& prim_growth) {
+  if (n_nodes == 0 || nodes.size() < (size_t)n_nodes * n_copies) return;
+  (void)growth_below(nodes, n_nodes, n_copies, root_ref, prim_growth);
 }
 
 void refit_bvh(std::vector<HostNode>& nodes, uint32_t root_ref, const std::vector<BuildPrim>& prims) {

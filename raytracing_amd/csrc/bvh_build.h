@@ -20,9 +20,9 @@ struct HostNode {  // 64 bytes, layout documented in scene_device.h
   float lmax[3];
   uint32_t right;
   float rmin[3];
-  uint32_t pad0;
-  float rmax[3];
-  uint32_t pad1;
+  float lgrow;  // how the left child's box grows with the distance to the ray origin (BOX_GROW_SPHERE / the smallest
+  float rmax[3];  // sphere radius below the child, 0 without spheres); filled in after the build (set_box_growth)
+  float rgrow;
 };
 static_assert(sizeof(HostNode) == 64, "node must be one 64-byte line");
 
@@ -86,5 +86,10 @@ std::vector<QuantNode> quantize_wide(const WideBvh& wide);
 // Recomputes every child box of a built tree (same nodes, same leaves) from other primitive boxes: `prims` in tree
 // order, as the build left them.  Used to fit one tree to the primitives' positions in several slices of time.
 void refit_bvh(std::vector<HostNode>& nodes, uint32_t root_ref, const std::vector<BuildPrim>& prims);
+
+// Fills in lgrow / rgrow of every node of a built tree (n_copies copies of n_nodes nodes, same tree): the largest
+// of prim_growth over the primitives below the child; prim_growth in tree order, one value per primitive.
+void set_box_growth(std::vector<HostNode>& nodes, uint32_t n_nodes, uint32_t n_copies, uint32_t root_ref,
+                    const std::vector<float>& prim_growth);
 
 }  // namespace mirt

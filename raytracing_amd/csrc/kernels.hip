@@ -30,16 +30,6 @@ constexpr float kInf = __builtin_huge_valf();
 constexpr float kPi = 3.14159265358979323846264338327950288f;
 constexpr float kTMin = 0.001f;  // renderer.rs:150
 
-// Boxes are grown by kBoxPad times the largest |coordinate| of the box
-// relative to the ray origin before the slab test.  The f32 sphere test of
-// the reference (objects.rs:42-56) reports hits for rays that miss the exact
-// sphere by up to ~sqrt(12*eps)*|origin-center| because of cancellation in
-// |os|^2 - r^2 and half_b^2 - a*c; the reference itself never culls
-// (aabb.rs:41-51 is always true on this path), so a box test that rejected
-// such a ray would change the result.  2^-8 leaves a 2.6x margin over that
-// bound with |origin-center| <= sqrt(3) * the max-norm distance used here.
-constexpr float kBoxPad = 0.00390625f;
-
 struct V3 {
   float x, y, z;
 };
@@ -286,14 +276,16 @@ __device__ __forceinline__ bool record_t(const SceneTables& tb, uint32_t index, 
 }
 
 // ---- conservative box test ------------------------------------------------------
-// Entry distance of the padded box, or miss.  inv = 1/d per component.
-__device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min, float t_max, float& t_near) {
+// Entry distance of the box grown by L * (L * growth + linear), L the largest |coordinate| of the box relative
+// to the ray origin (the rule and its constants: scene_device.h), or miss.  inv = 1/d per component.
+__device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min, float t_max, float growth, float linear,
+                                     float& t_near) {
   const V3 lo = bmin - o, hi = bmax - o;
   const float l = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))),
                         fmaxf(fabsf(lo.z), fabsf(hi.z)));
-  const float pad = l * kBoxPad;
+  const float pad = l * __builtin_fmaf(l, growth, linear);
   // (lo - pad) * inv and (hi + pad) * inv, the padding folded into one fused multiply-add per plane (this
-  // test only has to be conservative; its rounding is far inside the padding)
+  // test only has to be conservative; its rounding is part of the padding)
   const float ex = pad * inv.x, ey = pad * inv.y, ez = pad * inv.z;
   const float x0 = __builtin_fmaf(lo.x, inv.x, -ex), x1 = __builtin_fmaf(hi.x, inv.x, ex);
   const float y0 = __builtin_fmaf(lo.y, inv.y, -ey), y1 = __builtin_fmaf(hi.y, inv.y, ey);
@@ -390,8 +382,8 @@ __device__ __forceinline__ void node_step(Walk& w, const SceneTables& tb, float 
   const float4* n = tb.nodes + (w.node_base + 4 * (size_t)w.cur);
   const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
   float tl, tr;
-  const bool hl = slab(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, tl);
-  const bool hr = slab(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, tr);
+  const bool hl = slab(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, n2.w, BOX_GROW_LINEAR, tl);
+  const bool hr = slab(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, n3.w, BOX_GROW_LINEAR, tr);
   const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
   if (hl && hr) {
     const bool left_first = tl <= tr;
@@ -426,10 +418,10 @@ __device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float 
       v3(__builtin_fmaf(byte_of(hix, k), sx, q0.x), __builtin_fmaf(byte_of(hiy, k), sy, q0.y),                   \
          __builtin_fmaf(byte_of(hiz, k), sz, q0.z))
   float t0, t1, t2, t3;
-  const bool h0 = slab(MIRT_CHILD_BOX(0), w.r.o, w.inv, t_min, w.best_t, t0) && r0 != REF_NONE;
-  const bool h1 = slab(MIRT_CHILD_BOX(1), w.r.o, w.inv, t_min, w.best_t, t1) && r1 != REF_NONE;
-  const bool h2 = slab(MIRT_CHILD_BOX(2), w.r.o, w.inv, t_min, w.best_t, t2) && r2 != REF_NONE;
-  const bool h3 = slab(MIRT_CHILD_BOX(3), w.r.o, w.inv, t_min, w.best_t, t3) && r3 != REF_NONE;
+  const bool h0 = slab(MIRT_CHILD_BOX(0), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t0) && r0 != REF_NONE;
+  const bool h1 = slab(MIRT_CHILD_BOX(1), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t1) && r1 != REF_NONE;
+  const bool h2 = slab(MIRT_CHILD_BOX(2), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t2) && r2 != REF_NONE;
+  const bool h3 = slab(MIRT_CHILD_BOX(3), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t3) && r3 != REF_NONE;
 #undef MIRT_CHILD_BOX
   // entry distances are >= t_min > 0, so their bit patterns order like the numbers; a miss sorts behind every hit
   uint32_t k0 = h0 ? __float_as_uint(t0) : 0xFFFFFFFFu, k1 = h1 ? __float_as_uint(t1) : 0xFFFFFFFFu;

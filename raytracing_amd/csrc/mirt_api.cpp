@@ -631,6 +631,21 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     if (std::getenv("MIRT_VERBOSE"))
       std::fprintf(stderr, "mirt: folded into %u four-child nodes, height %u\n", n_nodes, s.bvh_height);
   }
+  if (!wide && n_nodes != 0) {
+    // Two-child trees (scenes the render kernel stages in LDS): how much each child box has to grow with the
+    // distance to the ray origin depends on the smallest sphere below it (scene_device.h, BOX_GROW_SPHERE).
+    std::vector<float> growth(build.size(), 0.0f);
+    for (size_t j = 0; j < build.size(); ++j) {
+      const uint32_t g = build[j].id;
+      if (g >= first_of_tag[TAG_RECT]) continue;  // rects and boxes: the linear part is enough
+      const float r = std::fabs(src[PRIM_QUADS * (size_t)g].w);
+      growth[j] = std::min(BOX_GROW_SPHERE / std::max(r, 1e-30f), 1e30f);
+    }
+    std::vector<HostNode> all((size_t)n_nodes * n_slices);
+    MIRT_HIP(ctx, hipMemcpy(all.data(), s.nodes.ptr, all.size() * sizeof(HostNode), hipMemcpyDeviceToHost));
+    set_box_growth(all, n_nodes, n_slices, root_ref, growth);
+    MIRT_HIP(ctx, hipMemcpy(s.nodes.ptr, all.data(), all.size() * sizeof(HostNode), hipMemcpyHostToDevice));
+  }
   if (std::getenv("MIRT_VERBOSE"))
     std::fprintf(stderr, "mirt: %s BVH build of %zu primitives: %.1f ms, %u nodes, height %u, %u time slice(s)\n",
                  builder == MIRT_BUILD_DEVICE_MORTON ? "device (Morton order)" : "host (surface-area)", build.size(),

@@ -47,9 +47,31 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 // BVH node, 64 bytes = 4 x float4:
 //   n0 = left.min.xyz,  bits(left ref)
 //   n1 = left.max.xyz,  bits(right ref)
-//   n2 = right.min.xyz, unused
-//   n3 = right.max.xyz, unused
+//   n2 = right.min.xyz, growth of the left box
+//   n3 = right.max.xyz, growth of the right box
 // Child boxes live in the parent so one 64-byte fetch decides both children.
+//
+// The box test must never reject a ray whose primitive test, in the reference's f32 arithmetic, reports a hit:
+// the reference itself never culls (aabb.rs:41-51 is always true on this path).  So every box is grown, per ray,
+// by  L * (L * growth + BOX_GROW_LINEAR),  L = the largest |coordinate| of the box relative to the ray origin:
+//  * Sphere test (objects.rs:42-56): with os = origin - centre, M = max(|os|, r) and u = 2^-24, the computed
+//    discriminant half_b^2 - a*c is off by at most 20 u M^2 |d|^2 from |d|^2 (r^2 - m^2), m the distance of the
+//    line from the centre.  A ray is therefore taken for a hit while it passes the sphere at up to 10 u M^2 / r,
+//    and the point at the root it reports lies within 20 u M^2 / r of the ball (the error of the square root,
+//    err / (2 |d| h) for a half-chord h, moves the point along the ray, h / r of which is radial; near a tangent
+//    the root is at most sqrt(40 u) M from the point of closest approach, s^2 / (2 r) radially).  M^2 <= 3 L^2,
+//    so growing by 90 u L^2 / r covers both; growth = BOX_GROW_SPHERE / r = 256 u / r leaves a factor 2.8, with r
+//    the smallest sphere radius below the box (a larger box has a larger L and a smaller r: its growth covers
+//    every sphere in it).
+//  * Rects and box sides (objects.rs:206-228): t = (k - o) / d and the point o + t d are off by at most
+//    4 u (|o| + L) <= 8 u L + 4 u |box|; wrapped primitives see a ray whose rotation and translation rounded by
+//    6 u |o|; the box test's own subtractions, reciprocals and fused multiply-adds are off by 4 u L.
+//    BOX_GROW_LINEAR = 64 u covers the parts in L, the builder's own padding of 170 u |box| (Bounds::pad) the rest.
+// Scenes walked from global memory keep the simpler rule  L * BOX_GROW_ANY  (sqrt(12 u) |os| for a sphere of any
+// radius, with a factor 2.6): their quantised boxes are looser than that anyway.
+constexpr float BOX_GROW_SPHERE = 1.52587890625e-05f;  // 2^-16
+constexpr float BOX_GROW_LINEAR = 3.814697265625e-06f;  // 2^-18
+constexpr float BOX_GROW_ANY = 0.00390625f;             // 2^-8
 
 // Primitive records: 4 x float4 = one 64-byte line per primitive, in the order the tree lists them
 // (so a leaf's primitives are neighbours); boundary-only primitives follow at the end.

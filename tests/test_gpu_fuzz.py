@@ -70,6 +70,45 @@ def test_random_sphere_fields_match_the_exhaustive_scan(scale, n, seed, builder,
     assert np.array_equal(t.view(np.uint32), want_t.view(np.uint32))
 
 
+@pytest.mark.parametrize("scale,seed,builder,far", [(1.0, 21, "host", 30.0), (1e3, 22, "host", 300.0), (1e-2, 23, "device", 30.0),
+                                                    (1.0, 24, "host", 3000.0)])
+def test_rays_that_graze_spheres_match_the_exhaustive_scan(scale, seed, builder, far, monkeypatch):
+    """Rays aimed at the rim of a sphere from up to thousands of radii away, passing it within a few times the
+    distance at which the f32 discriminant (objects.rs:46-50) can no longer tell a hit from a miss: the scan reports
+    hits for some rays that miss the exact sphere, and the boxes of the tree have to let every one of them through."""
+    monkeypatch.setenv("MIRT_BVH_BUILDER", builder)
+    rng = np.random.default_rng(seed)
+    n = 400
+    centers = (rng.uniform(-10, 10, (n, 3)) * scale).astype(F)
+    radii = (np.exp(rng.normal(-2.0, 1.2, n)) * scale).astype(F)           # 0.004 .. 5 times the scale
+    m = 60000
+    on = rng.integers(0, n, m)
+    c, r = centers[on].astype(np.float64), radii[on].astype(np.float64)[:, None]
+    u = rng.normal(size=(m, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)       # towards the rim ...
+    w = rng.normal(size=(m, 3))
+    v = np.cross(u, w); v /= np.linalg.norm(v, axis=1, keepdims=True)                # ... and along the tangent there
+    dist = np.exp(rng.uniform(np.log(0.5), np.log(far), (m, 1))) * scale
+    big = np.maximum(dist, r)
+    zone = 10.0 * 2.0 ** -24 * 3.0 * big * big / r                                    # where hit and miss blur
+    miss = rng.normal(size=(m, 1)) * np.minimum(2.0 * zone, 2e-3 * big)               # signed distance from the surface
+    rays = np.zeros((m, 7), F)
+    rays[:, 0:3] = (c + (r + miss) * u - dist * v).astype(F)
+    rays[:, 3:6] = (v * rng.uniform(0.05, 20.0, (m, 1))).astype(F)
+    ctx = Ctx()
+    try:
+        scene = ctx.upload(spheres=[sphere(tuple(cc), float(rr), order=i, ti=0, oi=i) for i, (cc, rr) in enumerate(zip(centers, radii))])
+        ti, oi, t = ctx.trace(scene, rays)
+    finally:
+        ctx.close()
+    want_i, want_t = scan(centers, radii, rays)
+    grazing = want_i == on                                                            # the sphere aimed at is the one hit
+    assert 0.1 < grazing.mean() < 0.9
+    got_i = np.where(ti == 0xFFFFFFFF, 0xFFFFFFFF, oi)
+    bad = np.nonzero(got_i != want_i)[0]
+    assert bad.size == 0, (bad.size, bad[:5], got_i[bad[:5]], want_i[bad[:5]], on[bad[:5]])
+    assert np.array_equal(t.view(np.uint32), want_t.view(np.uint32))
+
+
 def rect_scan(axis, a0, a1, b0, b1, k, o, d, t_min, t_max):
     """XYRect / XZRect / YZRect::hit (objects.rs:196-228, 251-283, 325-357): axis 0 = xy (k on z), 1 = xz (k on y),
     2 = yz (k on x); returns (accepted, t)."""
