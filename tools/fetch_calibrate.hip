@@ -3,7 +3,9 @@
 // larger than the 256 MiB Infinity Cache, or streams 64-byte path records in and out.  The byte counts are
 // known, so the counter's reading of these shapes can be corrected:
 //   rocprofv3 --pmc FETCH_SIZE -- ./fetch_calibrate ; rocprofv3 --pmc WRITE_SIZE -- ./fetch_calibrate
-// Kernels: k_gather64 (random 64-B records), k_stream64 (consecutive 64-B records, one per lane, read + written).
+// Kernels: k_gather64 (random 64-B records), k_stream64 (consecutive 64-B records, one per lane, read + written),
+// k_stream16 (records stored quad by quad: a wave reads and writes 64 consecutive 16-byte quads of each of four
+// arrays -- the layout of the path pool).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -38,6 +40,13 @@ __global__ void k_stream64(const float4* __restrict__ in, float4* __restrict__ o
   out[4 * i] = d; out[4 * i + 1] = c; out[4 * i + 2] = b; out[4 * i + 3] = a;
 }
 
+__global__ void k_stream16(const float4* __restrict__ in, float4* __restrict__ out, unsigned long long n_records) {
+  const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+  if (i >= n_records) return;
+  const float4 a = in[i], b = in[n_records + i], c = in[2 * n_records + i], d = in[3 * n_records + i];
+  out[i] = d; out[n_records + i] = c; out[2 * n_records + i] = b; out[3 * n_records + i] = a;
+}
+
 int main() {
   const unsigned long long n_records = 48ull << 20;  // 3 GiB of 64-byte records
   float4* table;
@@ -52,7 +61,11 @@ int main() {
   CHECK(hipDeviceSynchronize());
   hipLaunchKernelGGL(k_stream64, dim3((unsigned)(n_records / 256)), dim3(256), 0, 0, table, copy, n_records);
   CHECK(hipDeviceSynchronize());
-  std::printf("{\"k_gather64_bytes_read\": %llu, \"k_stream64_bytes_read\": %llu, \"k_stream64_bytes_written\": %llu}\n",
-              (unsigned long long)threads * rounds * 64ull, n_records * 64ull, n_records * 64ull);
+  hipLaunchKernelGGL(k_stream16, dim3((unsigned)(n_records / 256)), dim3(256), 0, 0, table, copy, n_records);
+  CHECK(hipDeviceSynchronize());
+  std::printf("{\"k_gather64_bytes_read\": %llu, \"k_stream64_bytes_read\": %llu, \"k_stream64_bytes_written\": %llu, "
+              "\"k_stream16_bytes_read\": %llu, \"k_stream16_bytes_written\": %llu}\n",
+              (unsigned long long)threads * rounds * 64ull, n_records * 64ull, n_records * 64ull, n_records * 64ull,
+              n_records * 64ull);
   return 0;
 }

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $O/cal_f -o f --output-format csv -- $R/tools/bin/fetch_calibrate > $O/cal_f.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $O/cal_w -o w --output-format csv -- $R/tools/bin/fetch_calibrate > $O/cal_w.log 2>&1
 tail -1 $O/cal_f.log
-grep -h -E "k_gather64|k_stream64" $O/cal_f/*counter_collection.csv $O/cal_w/*counter_collection.csv | cut -c1-300 > $O/calibration_rows.csv
+grep -h -E "k_gather64|k_stream64|k_stream16" $O/cal_f/*counter_collection.csv $O/cal_w/*counter_collection.csv | cut -c1-300 > $O/calibration_rows.csv
 cat $O/calibration_rows.csv | awk -F, '{print $(NF-1), $NF, $0}' | cut -c1-200
 cd $R
 timeout -k 10 500 python -u bench.py --scene synthetic_bvh:$HALF --spp $SPP --steps 2 --warmup 1 > $O/bench.json 2> $O/bench.err

@@ -23,4 +23,4 @@ grep -h k_render $O/pmc_f/*counter_collection.csv $O/pmc_w/*counter_collection.c
 cd $R
 timeout -k 10 120 python3 tools/phase_probe.py final_scene 32 > $O/phase_32.log 2>&1 || true
 timeout -k 10 120 python3 tools/phase_probe.py final_scene 64 > $O/phase_64.log 2>&1 || true
-tail -2 $O/phase_32.log $O/phase_64.log
+tail -n 2 $O/phase_32.log; tail -n 2 $O/phase_64.log
