@@ -190,10 +190,12 @@ def main():
     kernel_ms = [0.0] * R.MIRT_KERNEL_COUNT
     kernel_launches = [0] * R.MIRT_KERNEL_COUNT
     iterations = 0
+    pool_used = 0
     for _ in range(a.steps):
         st = step(flags)
         if st:
             iterations += st["iterations"]
+            pool_used = st["path_pool"]
             for k in range(R.MIRT_KERNEL_COUNT):
                 kernel_ms[k] += st["kernel_ms"][k]
                 kernel_launches[k] += st["kernel_launches"][k]
@@ -269,7 +271,7 @@ def main():
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.scene} {a.width}x{a.height}, {total_spp} spp, depth {depth}",
                        "sharding": f"sample ranges over {world} GPU(s), RCCL sum-reduce of the f32 image" if world > 1
-                       else "single GPU", "path_pool": ws["path_pool"], "seed": a.seed,
+                       else "single GPU", "path_pool": pool_used or ws["path_pool"], "seed": a.seed,
                        "rounds_per_step": iterations / max(1, a.steps)},
             "roofline": roofline, "work_models": models,
         }

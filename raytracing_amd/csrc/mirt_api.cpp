@@ -862,12 +862,28 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   const uint32_t regions = cfg.regions();
   // paths in flight: every wave's region a whole number of 64 slots, no more than the job has paths
   const uint32_t granule = regions * 64u;
-  uint64_t want = job.want_pool ? job.want_pool : (job.fixed_workspace ? STATIC_POOL_PATHS : (1u << 23));
+  // (left to the library: a thirty-second of the job's paths, between 8 Mi and 32 Mi -- 5 to 21 GB of records; the
+  // larger pool is worth 3.5 % on a 1024-spp 1080p frame, nothing on a 128-spp one)
+  uint64_t want = job.want_pool ? job.want_pool
+                  : job.fixed_workspace ? STATIC_POOL_PATHS
+                                        : std::min<uint64_t>(std::max<uint64_t>(total / 32, 1u << 23), 1u << 25);
   want = std::min<uint64_t>(want, total);
   want = std::min<uint64_t>(std::max<uint64_t>(want, granule), 1u << 27);
   const uint32_t pool = (uint32_t)((want + granule - 1) / granule * granule);
   job.rc.pool = pool;
   job.rc.region_cap = pool / regions;
+
+  // Large scenes (from 2^18 primitives): a ray takes at most `budget` steps per round; longer walks are put aside
+  // and go on in the next round, so the few rays that graze such a scene for thousands of steps no longer hold up
+  // every round.  Smaller scenes have no such rays and would only pay for the bookkeeping.
+  uint32_t step_budget = 0;
+  if (!cfg.lds_scene && !job.rays && (scene->n_prims >= (1u << 18) || std::getenv("MIRT_STEP_BUDGET"))) {
+    // (a step is one four-child node or one primitive test.  1 M spheres: 128 to 256 steps is best, +22 % over
+    // walking a thirty-second of the scene's diagonal per round and +85 % over whole rays; 10 M: 256 to 512)
+    long budget = 256;
+    if (const char* e = std::getenv("MIRT_STEP_BUDGET")) budget = std::strtol(e, nullptr, 10);  // tuning aid; 0 = whole rays
+    if (budget > 0) step_budget = (uint32_t)std::min<long>(budget, 1 << 30);
+  }
 
   Workspace ws;
   if (job.fixed_workspace) {
@@ -881,8 +897,9 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
     MIRT_HIP(ctx, ctx->state.ensure(sizeof(RenderState)));
     MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
     MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
-    const uint32_t save_cap = std::max(64u, job.rc.region_cap / 4);
-    MIRT_HIP(ctx, ctx->saves.ensure((size_t)2 * regions * save_cap * SAVE_QUADS * 16));
+    // (the save area is only there for walks with a step budget)
+    const uint32_t save_cap = step_budget ? std::max(64u, job.rc.region_cap / 4) : 0u;
+    MIRT_HIP(ctx, ctx->saves.ensure(std::max<size_t>(256, (size_t)2 * regions * save_cap * SAVE_QUADS * 16)));
     ws = Workspace{{ctx->paths[0].as<float4>(), ctx->paths[1].as<float4>()}, ctx->queues.as<float4>(),
                    ctx->state.as<RenderState>(), ctx->work.as<WorkCounters>(), ctx->args.as<RenderArgs>(),
                    ctx->saves.as<uint4>(), save_cap};
@@ -921,9 +938,6 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.rgb_sum = job.rgb_sum;
   args.refill_min = cfg.refill_min;
   args.waves_per_block = (uint32_t)cfg.block / 64u;
-  // Large scenes (from 2^18 primitives): a ray takes at most `budget` steps per round; longer walks are put aside
-  // and go on in the next round, so the few rays that graze such a scene for thousands of steps no longer hold up
-  // every round.  Smaller scenes have no such rays and would only pay for the bookkeeping.
   args.stack_overflow = nullptr;
   args.overflow_levels = 0;
   if (scene->view.wide && 3 * scene->view.bvh_height + 1 > (uint32_t)WIDE_LDS_STACK) {
@@ -933,16 +947,9 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
     MIRT_HIP(ctx, ctx->overflow.ensure((size_t)cfg.grid * args.overflow_levels * RENDER_THREADS * 4));
     args.stack_overflow = ctx->overflow.as<uint32_t>();
   }
-  args.step_budget = 0;
+  args.step_budget = step_budget;
   args.save_cap = ws.save_cap;
   args.saves = ws.saves;
-  if (!cfg.lds_scene && !job.rays && (scene->n_prims >= (1u << 18) || std::getenv("MIRT_STEP_BUDGET"))) {
-    // (a step is one four-child node or one primitive test.  1 M spheres: 128 to 256 steps is best, +22 % over
-    // walking a thirty-second of the scene's diagonal per round and +85 % over whole rays; 10 M: 256 to 512)
-    long budget = 256;
-    if (const char* e = std::getenv("MIRT_STEP_BUDGET")) budget = std::strtol(e, nullptr, 10);  // tuning aid; 0 = whole rays
-    if (budget > 0) args.step_budget = (uint32_t)std::min<long>(budget, 1 << 30);
-  }
   args.node_min = cfg.node_min;
   args.rays = job.rays;
   args.hit_type = job.hit_type;

@@ -1,7 +1,7 @@
 # throughput against samples per pixel and pool size (what one GPU of an N-GPU strong-scaling job sees)
-for spp in 128 256; do
-  for pool in 1048576 2097152 4194304 8388608; do
-    timeout -k 10 200 python -u bench.py --steps 4 --warmup 1 --spp $spp --pool $pool --no-cpu-baseline > gpurun_out/ps.json 2>gpurun_out/ps.err || { tail -3 gpurun_out/ps.err; exit 1; }
+for spp in 128 1024; do
+  for pool in 4194304 8388608 16777216 33554432; do
+    timeout -k 10 200 python -u bench.py --steps 3 --warmup 1 --spp $spp --pool $pool --no-cpu-baseline > gpurun_out/ps.json 2>gpurun_out/ps.err || { tail -3 gpurun_out/ps.err; exit 1; }
     python -c "
 import json; d=json.load(open('gpurun_out/ps.json')); print('spp', $spp, 'pool', $pool, round(d['value'],1), 'Msamples/s', round(d['ms_per_step'],2), 'ms/step', 'kernel', round(d['roofline']['avg_launch_ms'],2), 'rounds', d['config']['rounds_per_step'])"
   done
