@@ -385,7 +385,8 @@ int mirt_render_accumulate(mirt_context* ctx, const mirt_scene* scene, const mir
 
 /* mirt_render_accumulate for callers that may not allocate device memory (code under HIP graph capture, serving
  * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The path pool, the counters
- * and the launch arguments live in a fixed workspace the library holds on every GPU (about 40 MiB); the call
+ * and the launch arguments live in a fixed workspace the library holds on every GPU (46 MiB: 65 536 paths of 640
+ * bytes, a control page, and room for walks put aside); the call
  * makes no hipMalloc / hipFree and creates no events, so MIRT_RENDER_TIME_KERNELS is rejected.  The workspace holds
  * mirt_static_workspace_paths() paths in flight: params->path_pool = 0 uses all of them, a larger path_pool is
  * rejected with MIRT_ERR_INVALID_ARGUMENT (images of any size are rendered through the pool; the small pool makes
