@@ -64,6 +64,16 @@ def measured_traffic(scene, segments_per_launch):
     return None
 
 
+def measured_ceiling(shape):
+    """What the chip's memory system delivered to an access shape of the render kernel in a bare copy / gather kernel
+    (tools/fetch_calibrate.hip, committed run): information beside the spec peak the roofline is priced against."""
+    f = ROOT / "profiles" / "hbm_ceilings.json"
+    if not f.exists():
+        return None
+    m = json.loads(f.read_text()).get(shape)
+    return {"gb_per_s": m["gb_per_s"], "shape": m["shape"], "source": "profiles/hbm_ceilings.json"} if m else None
+
+
 def valu_issue(scene, segments, kernel_seconds):
     """Share of the chip's vector-instruction issue slots the launch used: VALU instructions per segment from the
     committed SQ counter run of this scene x this launch's segments x the measured issue cost of a wave64
@@ -255,11 +265,12 @@ def main():
                 if traffic is not None:
                     hbm = traffic / (ker_s / launches) / 1e9
                     roofline["hbm_measured"] = {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                "frac": hbm / HBM_PEAK_GBS}
+                                                "frac": hbm / HBM_PEAK_GBS, "copy_kernel": measured_ceiling("stream16")}
             else:
                 roofline = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                            "bytes_per_segment": bytes_per_segment, **common}
+                            "bytes_per_segment": bytes_per_segment, "gather_kernel": measured_ceiling("gather64"),
+                            **common}
             # both models side by side, whichever roof binds (informational)
             models = {"bytes_per_segment": bytes_per_segment, "algorithmic_gb_per_s": gbs,
                       "flops_per_segment": flops_per_segment, "algorithmic_tflop_per_s": tf,
