@@ -194,3 +194,50 @@ def test_random_mixed_scenes_match_the_exhaustive_scan(scale, seed):
     bad = np.nonzero(got_i != want_i)[0]
     assert bad.size == 0, (bad[:5], got_i[bad[:5]], want_i[bad[:5]], t[bad[:5]], want_t[bad[:5]])
     assert np.array_equal(t.view(np.uint32), want_t.view(np.uint32))
+
+
+@pytest.mark.parametrize("scale,seed", [(1.0, 31), (300.0, 32), (0.02, 33)])
+def test_rays_at_the_edges_and_corners_of_boxes_match_the_exhaustive_scan(scale, seed):
+    """Box3d::hit tests its six sides one after the other (objects.rs:396-436).  Rays aimed at edges and corners, where
+    two or three sides are met at (nearly) the same t, rays that start on a side or an edge, and rays that run inside
+    the plane of a side (a zero direction component: 0 / 0 and x / 0 in the sides' own tests) must come out as the
+    exhaustive scan has them: same box, same bits of t."""
+    rng = np.random.default_rng(seed)
+    prims, boxes = [], []
+    for i in range(300):
+        c = rng.uniform(-10, 10, 3) * scale
+        ext = rng.uniform(0.2, 3.0, 3) * scale
+        mn, mx = F(c), F(c + ext)
+        prims.append(("box", mn, mx))
+        boxes.append(R.Box(R.PrimHeader(0, 0, i, 0, i, 0), (C.c_float * 3)(*mn), (C.c_float * 3)(*mx)))
+    m = 40000
+    on = rng.integers(0, 300, m)
+    mn = np.array([prims[i][1] for i in on], np.float64)
+    mx = np.array([prims[i][2] for i in on], np.float64)
+    # a point of the box with every coordinate at the minimum, at the maximum or in between: corners, edges, sides
+    pick = rng.integers(0, 3, (m, 3))
+    pick[np.all(pick == 2, axis=1), 0] = 0                                   # (never an inner point)
+    target = np.where(pick == 0, mn, np.where(pick == 1, mx, mn + (mx - mn) * rng.uniform(0, 1, (m, 3))))
+    origin = target + rng.normal(size=(m, 3)) * scale * np.exp(rng.uniform(np.log(0.1), np.log(100.0), (m, 1)))
+    rays = np.zeros((m, 7), F)
+    rays[:, 0:3] = origin.astype(F)
+    rays[:, 3:6] = ((target - rays[:, 0:3].astype(np.float64)) * rng.uniform(0.05, 20.0, (m, 1))).astype(F)
+    k = m // 8
+    rays[:k, 0:3] = target[:k].astype(F)                                     # starting on the corner / edge / side itself ...
+    rays[:k, 3:6] = rng.normal(size=(k, 3)).astype(F)                        # ... in any direction
+    for axis in range(3):                                                    # inside the plane of a side, and along an edge
+        sel = slice(k + axis * 500, k + (axis + 1) * 500)
+        rays[sel, 3 + axis] = 0.0
+        rays[sel, axis] = np.where(rng.integers(0, 2, 500) == 0, mn[sel, axis], mx[sel, axis]).astype(F)
+    ctx = Ctx()
+    try:
+        scene = ctx.upload(boxes=boxes)
+        ti, oi, t = ctx.trace(scene, rays)
+    finally:
+        ctx.close()
+    want_i, want_t = mixed_scan(prims, rays)
+    assert 0.3 < (want_i != 0xFFFFFFFF).mean() < 1.0
+    got_i = np.where(ti == 0xFFFFFFFF, 0xFFFFFFFF, oi)
+    bad = np.nonzero(got_i != want_i)[0]
+    assert bad.size == 0, (bad.size, bad[:5], got_i[bad[:5]], want_i[bad[:5]], t[bad[:5]], want_t[bad[:5]])
+    assert np.array_equal(t.view(np.uint32), want_t.view(np.uint32))
