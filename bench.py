@@ -221,7 +221,7 @@ def main():
         samples_per_step = a.width * a.height * total_spp
         value = samples_per_step * a.steps / elapsed / 1e6
         # work per segment, from an instrumented pass outside the timed region (rank 0's share, few spp)
-        probe_spp = max(1, min(count, 4))
+        probe_spp = max(1, min(count, 32))
         ws = scene.render_accumulate(sums.data_ptr(), a.width, a.height, probe_spp, depth=depth, aspect=aspect,
                                      seed=a.seed, first_sample=first, path_pool=a.pool,
                                      flags=R.MIRT_RENDER_COUNT_WORK, stream=stream)

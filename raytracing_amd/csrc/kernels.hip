@@ -1778,12 +1778,21 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       const uint32_t n_free = A->rc.region_cap - n_surv;
       const unsigned long long total_paths = A->rc.total_paths;
       if (n_free != 0 && !exhausted) {
-        const unsigned long long first = atomicAdd(&A->state->issued, (unsigned long long)n_free);
+        // Towards the end of the render the waves take smaller helpings -- an equal share of what the counter had
+        // left when last looked at, rounded up to a wave's worth -- so that they all run dry together instead of
+        // some sitting idle while others work through a last full region.
+        unsigned long long take = n_free;
+        const unsigned long long seen = __hip_atomic_load(&A->state->issued, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen < total_paths) {
+          const unsigned long long share = ((total_paths - seen) / (gridDim.x * A->waves_per_block) + 64ull) & ~63ull;
+          if (share < take) take = share;
+        }
+        const unsigned long long first = atomicAdd(&A->state->issued, take);
         if (first < total_paths) {
           const unsigned long long left = total_paths - first;
-          fresh = left < n_free ? (uint32_t)left : n_free;
+          fresh = left < take ? (uint32_t)left : (uint32_t)take;
         }
-        exhausted = first + n_free >= total_paths;
+        exhausted = first + take >= total_paths;
         sh.first_new_lo = (uint32_t)first;
         sh.first_new_hi = (uint32_t)(first >> 32);
       }
