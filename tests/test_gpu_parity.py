@@ -150,6 +150,23 @@ def test_same_seed_images_match_per_pixel(scenes, name, size, spp):
     assert np.quantile(rel, 0.99) < 1e-3
 
 
+@pytest.mark.parametrize("size,spp", [((37, 23), 5), ((2, 2), 64), ((130, 7), 3), ((8, 61), 2)])
+def test_ragged_frames_match_the_oracle_per_pixel(scenes, size, spp):
+    """Frames whose sides are no multiple of the 8x8 tiles paths are started in, down to the smallest frame the
+    renderer accepts, with the smallest pool and a pool left to the library: same seed, same image as the oracle."""
+    g, o = scenes("spheres")
+    w, h = size
+    orgb, osums, _ = o.render(w, h, spp, seed=5)
+    for pool in (0, 1):                                    # (1: rounded up to the smallest pool there is)
+        rgb, sums, st = g.render(w, h, spp, seed=5, path_pool=pool)
+        assert st["samples"] == w * h * spp
+        ok = np.isfinite(osums) & np.isfinite(sums)
+        assert ok.mean() > 0.99
+        rel = np.abs(sums[ok] - osums[ok]) / (np.abs(osums[ok]) + 1e-3)
+        assert np.quantile(rel, 0.98) < 1e-3
+        assert float(np.mean(np.abs(rgb.astype(int) - orgb.astype(int)) > 1)) < 0.02
+
+
 @pytest.mark.parametrize("name", ["spheres", "cornel_box", "final_scene"])
 def test_converged_image_psnr_vs_cpu_fixture(scenes, name):
     """Independent seeds: GPU render (4x the fixture's spp) against the committed converged CPU image,
