@@ -1208,12 +1208,13 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       if (COUNT) ts = clock64();
       const uint32_t base = next_entry;
       float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
-      // the lanes that will be without work after the hand-in (a spent walk stays when the save area is full:
-      // its lane is then passed over although it was counted, and gets no ray either)
+      // The lanes that will be without work after the hand-in.  With the scene in LDS every ray that is done
+      // leaves, and the lanes' ranks are wanted now, ahead of the hand-in's stores; with a step budget a spent walk
+      // may have to stay (no room in the save area), so the lanes are counted after that is settled.
       const unsigned long long m_spent = LDS_SCENE ? 0ull : __ballot(spent);
-      const unsigned long long m_free = __ballot(done) | __ballot(slot == NO_SLOT);
-      const uint32_t n_free = (uint32_t)__popcll(m_free);
-      const uint32_t rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
+      unsigned long long m_free = __ballot(done) | __ballot(slot == NO_SLOT);
+      uint32_t n_free = (uint32_t)__popcll(m_free);
+      uint32_t rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
       if (AHEAD && more && base < n_stored) {
         // the rays the free lanes will take, out of the lanes that hold them, and the loads for the next exchange
         r0 = from_lane(ahead[0], rank << 2);
@@ -1244,6 +1245,11 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       }
       if (!LDS_SCENE) n_saved += (uint32_t)__popcll(m_spent);
       const bool leaving = q >= 0;
+      if (!LDS_SCENE) {
+        m_free = __ballot(leaving) | __ballot(slot == NO_SLOT);
+        n_free = (uint32_t)__popcll(m_free);
+        rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
+      }
       unsigned long long mq = 0ull;  // the lanes handing in to the same queue as this one
       uint32_t cnt = 0;
 #pragma unroll

@@ -284,6 +284,27 @@ def test_walks_put_aside_and_resumed_find_the_same_hits(budget, monkeypatch):
     assert abs(st["segments"] - oseg) <= max(8, oseg // 20000)
 
 
+def test_a_full_save_area_loses_no_ray(monkeypatch):
+    """More walks use up their budget in a round than the region's save area holds (a quarter of the region): the
+    ones that find no room walk on instead, and every path is still traced -- same segments, same steps, same image
+    as with whole-ray walks."""
+    name, w, h, spp = "synthetic_bvh:40", 640, 360, 4
+    g = R.ExampleScene(name)
+    try:
+        monkeypatch.setenv("MIRT_STEP_BUDGET", "0")
+        _, whole_sums, st0 = g.render(w, h, spp, seed=9, path_pool=1 << 20, flags=R.MIRT_RENDER_COUNT_WORK)
+        monkeypatch.setenv("MIRT_STEP_BUDGET", "2")        # every walk is spent at once: four times the save area
+        _, sums, st = g.render(w, h, spp, seed=9, path_pool=1 << 20, flags=R.MIRT_RENDER_COUNT_WORK)
+    finally:
+        g.close()
+    assert st["path_pool"] == 1 << 20                      # regions of 256 slots, save areas of 64
+    assert st["segments"] == st0["segments"]
+    assert st["nodes_visited"] == st0["nodes_visited"] and st["prims_tested"] == st0["prims_tested"]
+    ok = np.isfinite(sums) & np.isfinite(whole_sums)
+    assert np.array_equal(np.isfinite(sums), np.isfinite(whole_sums))
+    assert np.allclose(sums[ok], whole_sums[ok], rtol=1e-5, atol=1e-6)
+
+
 def test_large_scene_library_defaults(scenes):
     """A scene of more than 2^18 primitives with nothing overridden: the library picks the device (Morton order)
     builder and gives camera paths a step budget per round.  Closest-hit ids and t bits of caller rays against the oracle's
