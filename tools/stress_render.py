@@ -2,6 +2,7 @@
 """Many short renders with random frame sizes, sample counts, depths, pools and estimator flags on every example scene
 (and one scene walked from global memory): each must return, count every sample and leave no value of the wrong sign.
 usage: stress_render.py [runs] [seed]"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -26,8 +27,21 @@ for i in range(runs):
         flags |= R.MIRT_RENDER_COUNT_WORK
     seed = int(rng.integers(0, 1 << 31))
     first = int(rng.integers(0, 1000))
+    os.environ.pop("MIRT_STEP_BUDGET", None)
     rgb, sums, st = g.render(w, h, spp, depth=depth, seed=seed, first_sample=first, path_pool=pool, flags=flags)
     assert st["samples"] == w * h * spp, (name, w, h, spp, st)
+    if name.startswith("synthetic") and depth > 0 and rng.random() < 0.5:
+        # the same frame with a step budget per round: walks put aside and resumed must add up to the same steps
+        os.environ["MIRT_STEP_BUDGET"] = str(int(rng.integers(1, 60)))
+        c = R.MIRT_RENDER_COUNT_WORK
+        _, sums_b, st_b = g.render(w, h, spp, depth=depth, seed=seed, first_sample=first, path_pool=pool, flags=c)
+        os.environ["MIRT_STEP_BUDGET"] = "0"
+        _, sums_w, st_w = g.render(w, h, spp, depth=depth, seed=seed, first_sample=first, path_pool=pool, flags=c)
+        os.environ.pop("MIRT_STEP_BUDGET", None)
+        assert (st_b["segments"], st_b["nodes_visited"], st_b["prims_tested"]) == \
+               (st_w["segments"], st_w["nodes_visited"], st_w["prims_tested"]), (w, h, spp, depth, pool, st_b, st_w)
+        both = np.isfinite(sums_b) & np.isfinite(sums_w)
+        assert np.allclose(sums_b[both], sums_w[both], rtol=1e-4, atol=1e-5)
     finite = np.isfinite(sums)
     assert np.all(sums[finite] >= 0.0), (name, w, h, spp, depth)
     if depth == 0:
