@@ -216,6 +216,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # The frame of the last timed step (on rank 0, after the reduce: the whole frame) as an image: block means
+    # against the oracle's frame of the same size (tests/golden/<scene>_blocks.npz, when the workload is the one the
+    # fixture was made for).  Taken now, before the instrumented pass below adds its samples to the buffer.
+    golden = None
+    fixture = ROOT / "tests" / "golden" / f"{a.scene}_blocks.npz"
+    if rank == 0 and a.steps > 0 and fixture.exists():
+        import numpy as np
+        from raytracing_amd.imageops import compare_with_block_fixture
+        fx = np.load(fixture)
+        if (int(fx["width"]), int(fx["height"]), int(fx["depth"])) == (a.width, a.height, depth):
+            golden = compare_with_block_fixture(sums.cpu().numpy(), total_spp, fx)
+            golden["fixture"] = f"tests/golden/{fixture.name} (oracle, {int(fx['spp'])} spp per pixel)"
+
     result = None
     if rank == 0:
         samples_per_step = a.width * a.height * total_spp
@@ -294,21 +307,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(a.scene, a.width, a.height, depth)
         else:
             result["cpu_baseline"] = None
-        # The frame of the last timed step as an image: block means against the oracle's frame of the same size
-        # (tests/golden/<scene>_blocks.npz, when the workload is the one the fixture was made for).
-        fixture = ROOT / "tests" / "golden" / f"{a.scene}_blocks.npz"
-        result["golden"] = None
-        if fixture.exists():
-            import numpy as np
-            from raytracing_amd.imageops import compare_with_block_fixture
-            fx = np.load(fixture)
-            if (int(fx["width"]), int(fx["height"]), int(fx["depth"])) == (a.width, a.height, depth):
-                if world > 1:  # (after a reduce to rank 0 the buffer holds the whole frame there)
-                    pass
-                step(0)
-                torch.cuda.synchronize()
-                result["golden"] = compare_with_block_fixture(sums.cpu().numpy(), total_spp, fx)
-                result["golden"]["fixture"] = f"tests/golden/{fixture.name} (oracle, {int(fx['spp'])} spp per pixel)"
+        result["golden"] = golden
         if a.save:  # the frame of the last timed step
             img = rgb.cpu().numpy()
             with open(a.save, "wb") as f:
