@@ -532,6 +532,22 @@ void oracle_kat_dielectric(float ior, const float dir[3], const float normal[3],
 
 uint8_t oracle_kat_encode(float sum, uint32_t spp) { return encode_channel(sum, spp); }
 
+// The direction samplers (vec3.rs:62-88) on the stream of path (pixel 0, sample 0, bounce 0, shading stage) of
+// `seed`: kind 0 = random_cosine_direction, 1 = random_to_sphere(radius, distance_squared).  out = direction.
+void oracle_kat_direction(int kind, float radius, float distance_squared, uint64_t seed, float out[3]) {
+  Sampler sampler;
+  sampler.key[0] = (uint32_t)seed;
+  sampler.key[1] = (uint32_t)(seed >> 32);
+  sampler.begin(0, STAGE_SHADE);
+  tls_sampler() = &sampler;
+  const Vec3 d = kind == 0 ? random_cosine_direction() : random_to_sphere(radius, distance_squared);
+  out[0] = d.x; out[1] = d.y; out[2] = d.z;
+  tls_sampler() = nullptr;
+}
+
+// Schlick's approximation as the Dielectric uses it (material.rs:105-108).
+float oracle_kat_reflectance(float cosine, float ref_idx) { return Dielectric::reflectance(cosine, ref_idx); }
+
 static void put_hit(const HitRecord& h, float out[10]) {
   out[0] = h.t; out[1] = h.u; out[2] = h.v; out[3] = h.front_face ? 1.0f : 0.0f;
   out[4] = h.point.x; out[5] = h.point.y; out[6] = h.point.z;

@@ -254,6 +254,19 @@ def kat_dielectric(ior, direction, normal, front_face, seed=0):
     return out
 
 
+def kat_direction(kind, seed, radius=0.0, distance_squared=1.0):
+    """random_cosine_direction (kind 0) / random_to_sphere (kind 1) on the first two shading draws of path (0, 0, 0)."""
+    out = np.zeros(3, np.float32)
+    lib().oracle_kat_direction(kind, C.c_float(radius), C.c_float(distance_squared), C.c_uint64(seed), _ptr(out))
+    return out
+
+
+def kat_reflectance(cosine, ref_idx):
+    L = lib()
+    L.oracle_kat_reflectance.restype = C.c_float
+    return float(L.oracle_kat_reflectance(C.c_float(cosine), C.c_float(ref_idx)))
+
+
 def pixel_centre_rays(cam, width, height, time=0.5):
     """Rays through pixel centres, lens offset zero: u=(x+0.5)/(W-1), v=(y+0.5)/(H-1).
 

@@ -447,3 +447,69 @@ def test_checker_sign_of_the_product_of_sines():
     assert not O.kat_checker_is_odd([-0.1, -0.1, 0.1])
     assert O.kat_checker_is_odd([0.1, 0.1, 0.4])      # sin(4) < 0
     assert not O.kat_checker_is_odd([0.0, 0.1, 0.1])  # product 0 is not < 0
+
+
+@pytest.mark.parametrize("name,look_from,look_at,aspect,aperture", [
+    ("spheres", (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 16.0 / 9.0, 0.1),          # examples/spheres.rs:3,12-28
+    ("spheres_bvh", (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 16.0 / 9.0, 0.1),      # examples/spheres_bvh.rs:3,14-30
+    ("cornel_box", (478.0, 278.0, -600.0), (278.0, 278.0, 0.0), 1.0, 0.0),    # examples/cornel_box.rs:3,28-44
+    ("final_scene", (478.0, 278.0, -600.0), (278.0, 278.0, 0.0), 1.0, 0.0)])  # examples/final_scene.rs:4,18-34
+def test_camera_new_against_the_formulas_in_double_precision(name, look_from, look_at, aspect, aperture):
+    """Camera::new (camera.rs:30-56) for the four example programs: vfov 40, v_up (0,1,0), focus distance 10, shutter
+    [0, 1].  Expected values worked out here in float64 from the same formulas; the oracle computes in f32."""
+    cam, _ = O.Scene(name).camera()
+    lf, la, vup = np.array(look_from), np.array(look_at), np.array([0.0, 1.0, 0.0])
+    h = math.tan(math.radians(40.0) / 2.0)
+    vh, focus = 2.0 * h, 10.0
+    vw = aspect * vh
+    w = (lf - la) / np.linalg.norm(lf - la)
+    u = np.cross(vup, w); u /= np.linalg.norm(u)
+    v = np.cross(w, u)
+    hor, ver = focus * vw * u, focus * vh * v
+    llc = lf - 0.5 * hor - 0.5 * ver - focus * w
+    want = np.concatenate([lf, llc, hor, ver, u, v, w, [aperture / 2.0, 0.0, 1.0]])
+    assert cam.shape == (24,)
+    assert np.allclose(cam, want, rtol=2e-6, atol=2e-5), (cam, want)
+    # a ray through the middle of the image points at look_at (camera.rs:61-62 with no lens offset)
+    mid = (cam[3:6] + 0.5 * cam[6:9] + 0.5 * cam[9:12]) - cam[0:3]
+    assert np.allclose(mid / np.linalg.norm(mid), (la - lf) / np.linalg.norm(la - lf), atol=1e-5)
+
+
+def _shading_draws(seed, n=2):
+    """The first draws of the shading stage of path (pixel 0, sample 0, bounce 0): Philox4x32-10 on counter
+    (0, 0, 4 * 0 + 2, 0), each word's upper 24 bits scaled to [0, 1)."""
+    words = O.philox([0, 0, 2, 0], [seed & 0xFFFFFFFF, seed >> 32])
+    return [F(w >> 8) * F(1.0 / 16777216.0) for w in words[:n]]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 77])
+def test_random_cosine_direction_from_its_two_draws(seed):
+    """vec3.rs:62-74: z = sqrt(1 - r2), (x, y) = (cos, sin)(2 pi r1) sqrt(r2): a unit vector in the upper hemisphere."""
+    r1, r2 = _shading_draws(seed)
+    d = O.kat_direction(0, seed)
+    want = np.array([math.cos(2 * math.pi * r1) * math.sqrt(r2), math.sin(2 * math.pi * r1) * math.sqrt(r2),
+                     math.sqrt(1.0 - r2)])
+    assert np.allclose(d, want, atol=2e-6)
+    assert abs(float(np.linalg.norm(d.astype(np.float64))) - 1.0) < 1e-6 and d[2] >= 0
+
+
+@pytest.mark.parametrize("seed,radius,dist2", [(3, 1.0, 4.0), (4, 90.0, 250000.0), (5, 0.5, 0.2500001)])
+def test_random_to_sphere_stays_inside_the_cone_of_the_sphere(seed, radius, dist2):
+    """vec3.rs:76-88: z = 1 + r2 (cos_theta_max - 1) with cos_theta_max = sqrt(1 - R^2 / d^2), so z runs from 1 (the
+    centre) down to cos_theta_max (the rim); (x, y) on the circle of radius sqrt(1 - z^2)."""
+    r1, r2 = _shading_draws(seed)
+    d = O.kat_direction(1, seed, radius, dist2)
+    cos_max = math.sqrt(max(0.0, 1.0 - float(F(radius) * F(radius) / F(dist2))))
+    z = 1.0 + r2 * (cos_max - 1.0)
+    s = math.sqrt(max(0.0, 1.0 - z * z))
+    want = np.array([math.cos(2 * math.pi * r1) * s, math.sin(2 * math.pi * r1) * s, z])
+    assert np.allclose(d, want, atol=5e-4 if dist2 < 1 else 2e-6)      # (at the rim of a sphere seen from its surface 1 - z^2 cancels)
+    assert cos_max - 1e-6 <= d[2] <= 1.0 + 1e-6
+
+
+def test_schlick_reflectance_known_values():
+    """material.rs:105-108: r0 = ((1 - n) / (1 + n))^2, r0 + (1 - r0) (1 - cos)^5."""
+    assert O.kat_reflectance(1.0, 1.5) == pytest.approx(0.04, abs=1e-7)             # head on: r0 = (0.5 / 2.5)^2
+    assert O.kat_reflectance(0.0, 1.5) == pytest.approx(1.0, abs=1e-7)              # grazing: everything reflects
+    assert O.kat_reflectance(0.5, 1.5) == pytest.approx(0.04 + 0.96 / 32.0, abs=1e-7)
+    assert O.kat_reflectance(1.0, 1.0 / 1.5) == pytest.approx(0.04, abs=1e-7)       # the same from the inside
