@@ -276,14 +276,22 @@ __device__ __forceinline__ bool record_t(const SceneTables& tb, uint32_t index, 
 }
 
 // ---- conservative box test ------------------------------------------------------
-// Entry distance of the box grown by L * (L * growth + linear), L the largest |coordinate| of the box relative
-// to the ray origin (the rule and its constants: scene_device.h), or miss.  inv = 1/d per component.
+// Entry distance of the grown box, or miss (the rules and their constants: scene_device.h).  BY_RADIUS: the box
+// grows by L * (L * growth + linear), L the largest |coordinate| of the box relative to the ray origin; otherwise
+// by linear * |farthest corner|, the rule for spheres of any radius.  inv = 1/d per component.
+template <bool BY_RADIUS>
 __device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min, float t_max, float growth, float linear,
                                      float& t_near) {
   const V3 lo = bmin - o, hi = bmax - o;
-  const float l = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))),
-                        fmaxf(fabsf(lo.z), fabsf(hi.z)));
-  const float pad = l * __builtin_fmaf(l, growth, linear);
+  const float mx = fmaxf(fabsf(lo.x), fabsf(hi.x)), my = fmaxf(fabsf(lo.y), fabsf(hi.y)), mz = fmaxf(fabsf(lo.z), fabsf(hi.z));
+  float pad;
+  if (BY_RADIUS) {
+    const float l = fmaxf(fmaxf(mx, my), mz);
+    pad = l * __builtin_fmaf(l, growth, linear);
+  } else {
+    // (v_sqrt_f32: one unit in the last place, part of the constant's margin)
+    pad = linear * __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx)));
+  }
   // (lo - pad) * inv and (hi + pad) * inv, the padding folded into one fused multiply-add per plane (this
   // test only has to be conservative; its rounding is part of the padding)
   const float ex = pad * inv.x, ey = pad * inv.y, ez = pad * inv.z;
@@ -382,8 +390,8 @@ __device__ __forceinline__ void node_step(Walk& w, const SceneTables& tb, float 
   const float4* n = tb.nodes + (w.node_base + 4 * (size_t)w.cur);
   const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
   float tl, tr;
-  const bool hl = slab(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, n2.w, BOX_GROW_LINEAR, tl);
-  const bool hr = slab(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, n3.w, BOX_GROW_LINEAR, tr);
+  const bool hl = slab<true>(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, n2.w, BOX_GROW_LINEAR, tl);
+  const bool hr = slab<true>(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, n3.w, BOX_GROW_LINEAR, tr);
   const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
   if (hl && hr) {
     const bool left_first = tl <= tr;
@@ -418,10 +426,10 @@ __device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float 
       v3(__builtin_fmaf(byte_of(hix, k), sx, q0.x), __builtin_fmaf(byte_of(hiy, k), sy, q0.y),                   \
          __builtin_fmaf(byte_of(hiz, k), sz, q0.z))
   float t0, t1, t2, t3;
-  const bool h0 = slab(MIRT_CHILD_BOX(0), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t0) && r0 != REF_NONE;
-  const bool h1 = slab(MIRT_CHILD_BOX(1), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t1) && r1 != REF_NONE;
-  const bool h2 = slab(MIRT_CHILD_BOX(2), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t2) && r2 != REF_NONE;
-  const bool h3 = slab(MIRT_CHILD_BOX(3), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t3) && r3 != REF_NONE;
+  const bool h0 = slab<false>(MIRT_CHILD_BOX(0), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t0) && r0 != REF_NONE;
+  const bool h1 = slab<false>(MIRT_CHILD_BOX(1), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t1) && r1 != REF_NONE;
+  const bool h2 = slab<false>(MIRT_CHILD_BOX(2), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t2) && r2 != REF_NONE;
+  const bool h3 = slab<false>(MIRT_CHILD_BOX(3), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t3) && r3 != REF_NONE;
 #undef MIRT_CHILD_BOX
   // entry distances are >= t_min > 0, so their bit patterns order like the numbers; a miss sorts behind every hit
   uint32_t k0 = h0 ? __float_as_uint(t0) : 0xFFFFFFFFu, k1 = h1 ? __float_as_uint(t1) : 0xFFFFFFFFu;

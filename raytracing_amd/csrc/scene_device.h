@@ -67,11 +67,17 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 //    4 u (|o| + L) <= 8 u L + 4 u |box|; wrapped primitives see a ray whose rotation and translation rounded by
 //    6 u |o|; the box test's own subtractions, reciprocals and fused multiply-adds are off by 4 u L.
 //    BOX_GROW_LINEAR = 64 u covers the parts in L, the builder's own padding of 170 u |box| (Bounds::pad) the rest.
-// Scenes walked from global memory keep the simpler rule  L * BOX_GROW_ANY  (sqrt(12 u) |os| for a sphere of any
-// radius, with a factor 2.6): their quantised boxes are looser than that anyway.
+// Scenes walked from global memory use the bound that holds for a sphere of any radius,  BOX_GROW_ANY * F,  F the
+// Euclidean length of the box's farthest |coordinates| relative to the ray origin (F >= M: the box holds the ball):
+// the reported point P has |P - centre|^2 = r^2 + e + 2 h e_t + e_t^2, with e the discriminant's error (at most
+// 20 u M^2), h <= sqrt(r^2 + e) the computed half-chord and e_t <= 17 u M the error of the root along the ray;
+// sqrt(r^2 + A + B r) - r <= sqrt(A) + B / 2 with A = 20.1 u M^2, B = 34 u M puts P within 1.094e-3 M of the
+// ball, the rounding of origin - centre (u M) added: 1.095e-3 M.  BOX_GROW_ANY = 1.15e-3 leaves 5 % -- a hundred
+// times what the box test's own rounding (4 u F), its one-instruction square root and the decoded box's rounding
+// (outwards, by the builder) take.  For rects and box sides 1.15e-3 F is far more than the 64 u L they need.
 constexpr float BOX_GROW_SPHERE = 1.52587890625e-05f;  // 2^-16
 constexpr float BOX_GROW_LINEAR = 3.814697265625e-06f;  // 2^-18
-constexpr float BOX_GROW_ANY = 0.00390625f;             // 2^-8
+constexpr float BOX_GROW_ANY = 1.15e-3f;
 
 // Primitive records: 4 x float4 = one 64-byte line per primitive, in the order the tree lists them
 // (so a leaf's primitives are neighbours); boundary-only primitives follow at the end.
