@@ -284,6 +284,11 @@ def main():
                             "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                             "bytes_per_segment": bytes_per_segment, "gather_kernel": measured_ceiling("gather64"),
                             **common}
+                if traffic is not None:
+                    # what reached HBM: the L2 and the Infinity Cache serve the lines of the tree many rays share
+                    hbm = traffic / (ker_s / launches) / 1e9
+                    roofline["hbm_measured"] = {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": hbm / HBM_PEAK_GBS}
             # both models side by side, whichever roof binds (informational)
             models = {"bytes_per_segment": bytes_per_segment, "algorithmic_gb_per_s": gbs,
                       "flops_per_segment": flops_per_segment, "algorithmic_tflop_per_s": tf,

@@ -72,11 +72,13 @@ def test_random_sphere_fields_match_the_exhaustive_scan(scale, n, seed, builder,
 
 @pytest.mark.parametrize("scale,seed,builder,far,n", [(1.0, 21, "host", 30.0, 400), (1e3, 22, "host", 300.0, 400),
                                                       (1e-2, 23, "device", 30.0, 400), (1.0, 24, "host", 3000.0, 400),
-                                                      (1.0, 25, "host", 3000.0, 4500), (10.0, 26, "device", 300.0, 4500)])
+                                                      (1.0, 25, "host", 3000.0, 4500), (10.0, 26, "device", 300.0, 4500),
+                                                      (1.0, 27, "host", 30000.0, 4500), (0.1, 28, "device", 30000.0, 4500)])
 def test_rays_that_graze_spheres_match_the_exhaustive_scan(scale, seed, builder, far, n, monkeypatch):
     """Rays aimed at the rim of a sphere from up to thousands of radii away, passing it within a few times the
     distance at which the f32 discriminant (objects.rs:46-50) can no longer tell a hit from a miss: the scan reports
-    hits for some rays that miss the exact sphere, and the boxes of the tree have to let every one of them through."""
+    hits for some rays that miss the exact sphere, and the boxes of the tree have to let every one of them through.
+    (far = 30000: from there the whole field lies inside the blur of every sphere in it.)"""
     monkeypatch.setenv("MIRT_BVH_BUILDER", builder)
     rng = np.random.default_rng(seed)
     # (4500 spheres: too many for the LDS copy, so the tree is folded into four-child nodes with quantised boxes and
