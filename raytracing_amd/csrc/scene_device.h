@@ -55,27 +55,30 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 // the reference itself never culls (aabb.rs:41-51 is always true on this path).  So every box is grown, per ray,
 // by  L * (L * growth + BOX_GROW_LINEAR),  L = the largest |coordinate| of the box relative to the ray origin:
 //  * Sphere test (objects.rs:42-56): with os = origin - centre, M = max(|os|, r) and u = 2^-24, the computed
-//    discriminant half_b^2 - a*c is off by at most 20 u M^2 |d|^2 from |d|^2 (r^2 - m^2), m the distance of the
-//    line from the centre.  A ray is therefore taken for a hit while it passes the sphere at up to 10 u M^2 / r,
-//    and the point at the root it reports lies within 20 u M^2 / r of the ball (the error of the square root,
-//    err / (2 |d| h) for a half-chord h, moves the point along the ray, h / r of which is radial; near a tangent
-//    the root is at most sqrt(40 u) M from the point of closest approach, s^2 / (2 r) radially).  M^2 <= 3 L^2,
-//    so growing by 90 u L^2 / r covers both; growth = BOX_GROW_SPHERE / r = 256 u / r leaves a factor 2.8, with r
-//    the smallest sphere radius below the box (a larger box has a larger L and a smaller r: its growth covers
-//    every sphere in it).
+//    discriminant half_b^2 - a*c is off by e, |e| <= 20 u M^2 |d|^2, from |d|^2 (r^2 - m^2), m the distance of the
+//    line from the centre (17 u by first-order count: 7 u from half_b^2, 9 u from a*c, 1 u from the subtraction).
+//    Take |d| = 1.  The root the test reports is off by e_t <= 17 u M along the ray (half_b, the subtraction, the
+//    division by a), so the point P it stands for has  |P - centre|^2 = m^2 + (sqrt(disc) + e_t)^2 =
+//    r^2 + e + 2 h e_t + e_t^2 + 2 u h^2,  h <= sqrt(r^2 + e) the computed half-chord: with A = 20.1 u M^2 and
+//    B = 36 u M,  |P - centre| - r <= sqrt(r^2 + A + B r) - r.
+//      - Any radius: that is at most sqrt(A) + B / 2 = 1.094e-3 M; the rounding of origin - centre (u M) added,
+//        P lies within 1.095e-3 M of the ball.
+//      - A given radius: it is also at most (A + B r) / (2 r), so P lies within 10.05 u M^2 / r + 19 u M.
+//    Scenes staged in LDS use the second: M^2 <= 3 L^2 makes it 30.2 u L^2 / r + 33 u L, and growth =
+//    BOX_GROW_SPHERE / r = 64 u / r leaves a factor 2.1 on the quadratic part, with r the smallest sphere radius
+//    below the box (a larger box has a larger L and a smaller r: its growth covers every sphere in it).
 //  * Rects and box sides (objects.rs:206-228): t = (k - o) / d and the point o + t d are off by at most
 //    4 u (|o| + L) <= 8 u L + 4 u |box|; wrapped primitives see a ray whose rotation and translation rounded by
 //    6 u |o|; the box test's own subtractions, reciprocals and fused multiply-adds are off by 4 u L.
-//    BOX_GROW_LINEAR = 64 u covers the parts in L, the builder's own padding of 170 u |box| (Bounds::pad) the rest.
-// Scenes walked from global memory use the bound that holds for a sphere of any radius,  BOX_GROW_ANY * F,  F the
-// Euclidean length of the box's farthest |coordinates| relative to the ray origin (F >= M: the box holds the ball):
-// the reported point P has |P - centre|^2 = r^2 + e + 2 h e_t + e_t^2, with e the discriminant's error (at most
-// 20 u M^2), h <= sqrt(r^2 + e) the computed half-chord and e_t <= 17 u M the error of the root along the ray;
-// sqrt(r^2 + A + B r) - r <= sqrt(A) + B / 2 with A = 20.1 u M^2, B = 34 u M puts P within 1.094e-3 M of the
-// ball, the rounding of origin - centre (u M) added: 1.095e-3 M.  BOX_GROW_ANY = 1.15e-3 leaves 5 % -- a hundred
-// times what the box test's own rounding (4 u F), its one-instruction square root and the decoded box's rounding
-// (outwards, by the builder) take.  For rects and box sides 1.15e-3 F is far more than the 64 u L they need.
-constexpr float BOX_GROW_SPHERE = 1.52587890625e-05f;  // 2^-16
+//    BOX_GROW_LINEAR = 64 u covers the parts in L (spheres 33 u + 4 u, rects 8 u + 4 u), the builder's own padding
+//    of 170 u |box| (Bounds::pad) the rest.
+// Scenes walked from global memory use the first, BOX_GROW_ANY * F, F the Euclidean length of the box's farthest
+// |coordinates| relative to the ray origin (F >= M: the box holds the ball): BOX_GROW_ANY = 1.15e-3 leaves 5 % --
+// a hundred times what the box test's own rounding (4 u F), its one-instruction square root and the decoded box's
+// rounding (outwards, by the builder) take.  For rects and box sides 1.15e-3 F is far more than the 64 u L they
+// need.  (At a thousand units from a sphere of radius 0.2 the second bound would be 3 units: there the f32 test no
+// longer resolves r^2 in |os|^2 - r^2, and the first bound, 1.1 units, is what it really reports as hits.)
+constexpr float BOX_GROW_SPHERE = 3.814697265625e-06f;  // 2^-18
 constexpr float BOX_GROW_LINEAR = 3.814697265625e-06f;  // 2^-18
 constexpr float BOX_GROW_ANY = 1.15e-3f;
 
