@@ -652,4 +652,40 @@ int oracle_kat_aabb_hit(const float box[6], const float ray[7], float t_min, flo
   return b.hit(Ray(Point3(ray[0], ray[1], ray[2]), Vec3(ray[3], ray[4], ray[5]), ray[6]), t_min, t_max) ? 1 : 0;
 }
 
+// renderer.rs:140-190 in a furnace: a Lambertian floor (albedo a) under a sky of radiance b and a lamp that emits the
+// same b downwards (FlipFace(XZRect(DiffuseLight)), as in cornel_box.rs:79-86), sampled through the light list --
+// the lamp alone, or with_sphere a World of the lamp and a glowing ball, one object of each type as in
+// cornel_box.rs:12-26.  Every direction the mixture picks brings back b, so the mean of ray_color over the floor is
+// a * b whatever the densities are, as long as pdf.rs:81-91 and objects.rs:82-100,292-309 agree with each other.
+// Returns the mean of n paths that start above the floor and look down at it.
+float oracle_kat_furnace(int with_sphere, float a, float b, uint32_t n, uint64_t seed) {
+  const LambSolid grey(SolidTexture::from_rgb(a, a, a));
+  const DiffuseLight<SolidTexture> glow(SolidTexture::from_rgb(b, b, b));
+  World world;
+  world.add(XZRect<LambSolid>(-40.0f, 40.0f, -80.0f, 0.0f, -1.0f, grey));
+  world.add(FlipFace<XZRect<DiffuseLight<SolidTexture>>>(
+      XZRect<DiffuseLight<SolidTexture>>(-1.0f, 1.0f, -5.0f, -3.0f, 1.5f, glow)));
+  if (with_sphere) world.add(Sphere<DiffuseLight<SolidTexture>>(Point3(2.0f, 0.0f, -4.0f), 0.5f, glow));
+  const XZRect<LambSolid> lamp(-1.0f, 1.0f, -5.0f, -3.0f, 1.5f, grey);
+  World list;
+  list.add(XZRect<LambSolid>(-1.0f, 1.0f, -5.0f, -3.0f, 1.5f, grey));
+  list.add(Sphere<LambSolid>(Point3(2.0f, 0.0f, -4.0f), 0.5f, grey));
+  const Hittable* lights = with_sphere ? static_cast<const Hittable*>(&list) : static_cast<const Hittable*>(&lamp);
+  Sampler sampler;
+  sampler.key[0] = (uint32_t)seed;
+  sampler.key[1] = (uint32_t)(seed >> 32);
+  tls_sampler() = &sampler;
+  double sum = 0.0;
+  for (uint32_t i = 0; i < n; ++i) {
+    sampler.pixel = i;
+    sampler.sample = 0;
+    sampler.begin(0, STAGE_CAMERA);
+    const float x = rand_range(-1.0f, 1.0f), z = rand_range(-1.0f, -0.3f);
+    const Ray r(Point3(0.0f, 0.5f, 0.0f), Vec3(x, -1.0f, z), 0.0f);
+    sum += ray_color(r, world, 3, 0, Color(b, b, b), lights).x;
+  }
+  tls_sampler() = nullptr;
+  return (float)(sum / n);
+}
+
 }  // extern "C"

@@ -267,6 +267,13 @@ def kat_reflectance(cosine, ref_idx):
     return float(L.oracle_kat_reflectance(C.c_float(cosine), C.c_float(ref_idx)))
 
 
+def kat_furnace(with_sphere, albedo, radiance, n, seed=0):
+    L = lib()
+    L.oracle_kat_furnace.restype = C.c_float
+    L.oracle_kat_furnace.argtypes = [C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint64]
+    return float(L.oracle_kat_furnace(int(with_sphere), albedo, radiance, n, seed))
+
+
 def pixel_centre_rays(cam, width, height, time=0.5):
     """Rays through pixel centres, lens offset zero: u=(x+0.5)/(W-1), v=(y+0.5)/(H-1).
 

@@ -262,3 +262,60 @@ def test_long_light_lists_sample_the_same_light(ctx):
         assert np.isfinite(other).all()
         assert not np.array_equal(other, images[0])
         assert abs(other[30:].mean() - lit.mean()) < 0.03 * lit.mean()
+
+
+@pytest.mark.parametrize("kind,param", [(0, 0.0), (1, 0.0), (2, 1.5)])
+def test_a_convex_body_under_a_uniform_sky_has_closed_form_radiance(ctx, kind, param):
+    """renderer.rs:140-190 by hand.  One sphere under a constant background B: a scattered ray cannot meet a convex
+    body again, so a camera path is worth B when it misses and albedo * B when it hits -- for a Lambertian surface
+    scattering_pdf / pdf is exactly 1 (material.rs:50-57 against pdf.rs:25-32), for a mirror the attenuation is the
+    albedo (material.rs:75-91) -- and a glass ball (attenuation 1, material.rs:111-137) cannot be seen at all.
+    Every pixel therefore sums to k * albedo * B + (spp - k) * B with a whole number k of its samples on the ball."""
+    albedo = np.array([0.5, 0.25, 0.75], F)
+    bg = np.array([0.25, 0.5, 1.0], F)
+    mats = [R.Material(kind, 0, param)]
+    tex = [R.Texture(0, (C.c_float * 3)(*albedo), 0, 0, 0.0, 0)]
+    scene = ctx.upload(spheres=[sphere((0, 0, -3), 0.75, 0)], materials=mats, textures=tex)
+    spp = 4
+    _, sums, _ = ctx.render(scene, 32, 32, spp, depth=50, bg=tuple(bg))
+    if kind == 2:
+        assert np.allclose(sums, spp * bg, rtol=1e-6, atol=0)
+        return
+    k = (spp * bg[0] - sums[..., 0]) / (bg[0] * (1.0 - albedo[0]))       # samples on the ball, from the red channel
+    assert np.all(np.abs(k - np.round(k)) < 1e-4)
+    k = np.round(k)[..., None]
+    assert k.min() == 0 and k.max() == spp
+    assert np.allclose(sums, k * albedo * bg + (spp - k) * bg, rtol=2e-6, atol=0)
+    assert np.all(k[14:18, 14:18] == spp) and np.all(k[0] == 0)
+
+
+@pytest.mark.parametrize("with_sphere", [False, True])
+def test_light_sampling_keeps_a_furnace_in_balance(ctx, with_sphere):
+    """A floor under a sky of radiance B and a lamp that emits the same B downwards: whatever direction the mixture
+    of light and cosine sampling picks (pdf.rs:81-91, objects.rs:292-309), it brings back B, so the floor's expected
+    radiance is albedo * B (renderer.rs:166-183) -- a wrong density in either half of the mixture would tilt it.
+    with_sphere: the light list is a World of the lamp and a glowing ball, one object of each type as in the
+    Cornell box (world.rs:100-117, objects.rs:82-100)."""
+    b, albedo, spp = 0.5, 0.5, 256
+    mats = [R.Material(0, 0, 0.0), R.Material(3, 1, 0.0)]                                  # lambertian floor, light
+    tex = [R.Texture(0, (C.c_float * 3)(albedo, albedo, albedo), 0, 0, 0.0, 0), R.Texture(0, (C.c_float * 3)(b, b, b), 0, 0, 0.0, 0)]
+    ops = [R.ChainOp(2, (C.c_float * 3)(0, 0, 0))]                                         # FlipFace: emits downwards
+    chains = [R.Chain(0, 0), R.Chain(0, 1)]
+    floor = R.Rect(hdr(0, 0, 0), 1, -40.0, 40.0, -80.0, 0.0, -1.0)                         # XZ rect at y = -1
+    lamp = R.Rect(hdr(1, 1, 0, material=1, chain=1), 1, -1.0, 1.0, -5.0, -3.0, 1.5)        # XZ rect at y = 1.5
+    lights = [R.Light(0, (C.c_float * 5)(-1.0, 1.0, -5.0, -3.0, 1.5))]
+    kw = dict(lights=lights, lights_mode=1)
+    if with_sphere:
+        kw = dict(spheres=[sphere((2.0, 0.0, -4.0), 0.5, 2, ti=2, oi=0, material=1)],
+                  lights=lights + [R.Light(1, (C.c_float * 5)(2.0, 0.0, -4.0, 0.5, 0.0))],
+                  light_groups=[R.LightGroup(0, 1), R.LightGroup(1, 1)], lights_mode=2)
+    scene = ctx.upload(rects=[floor, lamp], materials=mats, textures=tex, chains=chains, chain_ops=ops, **kw)
+    cam = simple_camera()
+    cam.origin[:] = [0, 0.5, 0]
+    cam.lower_left_corner[:] = [-1, -1.5, -1]                                              # looks down at the floor
+    _, sums, _ = ctx.render(scene, 48, 48, spp, depth=3, bg=(b, b, b), cam=cam)
+    assert np.isfinite(sums).all()
+    floor_rows = sums[36:] / spp                                                           # the floor in front of the camera
+    assert abs(floor_rows.mean() - albedo * b) < 0.01 * albedo * b, floor_rows.mean()
+    per_pixel = floor_rows.mean(axis=2)
+    assert np.all(np.abs(per_pixel - albedo * b) < 0.25 * albedo * b)                      # no pixel far off either

@@ -513,3 +513,12 @@ def test_schlick_reflectance_known_values():
     assert O.kat_reflectance(0.0, 1.5) == pytest.approx(1.0, abs=1e-7)              # grazing: everything reflects
     assert O.kat_reflectance(0.5, 1.5) == pytest.approx(0.04 + 0.96 / 32.0, abs=1e-7)
     assert O.kat_reflectance(1.0, 1.0 / 1.5) == pytest.approx(0.04, abs=1e-7)       # the same from the inside
+
+
+@pytest.mark.parametrize("with_sphere", [False, True])
+def test_light_sampling_keeps_a_furnace_in_balance(with_sphere):
+    """renderer.rs:166-183 with the mixture of pdf.rs:81-91: under a sky and lights of one radiance b the floor's
+    expected radiance is albedo * b whichever way directions are drawn, provided the densities of
+    objects.rs:82-100, 292-309 and world.rs:100-117 match the way they are drawn."""
+    got = O.kat_furnace(with_sphere, 0.5, 0.5, 200000, seed=11)
+    assert abs(got - 0.25) < 0.0025, got
