@@ -319,3 +319,28 @@ def test_light_sampling_keeps_a_furnace_in_balance(ctx, with_sphere):
     assert abs(floor_rows.mean() - albedo * b) < 0.01 * albedo * b, floor_rows.mean()
     per_pixel = floor_rows.mean(axis=2)
     assert np.all(np.abs(per_pixel - albedo * b) < 0.25 * albedo * b)                      # no pixel far off either
+
+
+def test_an_absorbing_medium_transmits_two_to_the_minus_density_times_chord(ctx):
+    """transforms.rs:152-158: the free flight is -1/density * log2(draw) -- base 2 -- so a ray crosses a chord of length
+    l of the medium with probability 2^(-density * l), not e^(-density * l).  An Isotropic phase function absorbs
+    (material.rs:172-180), so under a white sky the pixel is that probability."""
+    rho, radius, spp = 0.5, 1.0, 1024
+    ball = sphere((0, 0, -3), radius, 0, flags=1)                                          # boundary only
+    mats = [R.Material(0, 0, 0.0), R.Material(4, 0, 0.0)]                                  # (unused), isotropic
+    smoke = R.Medium(0, 0, -1.0 / rho, 1, 0, 0, 5, 0)
+    scene = ctx.upload(spheres=[ball], materials=mats, media=[smoke])
+    n = 32
+    _, sums, _ = ctx.render(scene, n, n, spp, depth=5, bg=(1.0, 1.0, 1.0))
+    got = sums[..., 0] / spp
+    centre = -1.0 + 2.0 * (np.arange(n) + 0.5) / (n - 1)                                   # renderer.rs:216-217
+    dx, dy = np.meshgrid(centre, centre[::-1])                                             # row 0 is the top
+    d = np.stack([dx, dy, -np.ones_like(dx)], axis=-1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    c = np.array([0.0, 0.0, -3.0])
+    m2 = np.sum(np.cross(np.broadcast_to(c, d.shape), d) ** 2, axis=-1)                    # squared distance of the line from the centre
+    chord = 2.0 * np.sqrt(np.maximum(radius ** 2 - m2, 0.0))
+    want = 2.0 ** (-rho * chord)
+    assert abs(got[12:20, 12:20].mean() - want[12:20, 12:20].mean()) < 0.01
+    assert abs(want[16, 16] - 0.5) < 0.01 and abs(got[14:18, 14:18].mean() - 0.5) < 0.02  # through the centre: 2^-1, not e^-1 = 0.37
+    assert np.all(got[0] == 1.0)                                                           # beside the ball: the sky
