@@ -1947,7 +1947,8 @@ RenderConfig plan_render(const DeviceScene& sc) {
   // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes;
   // bookkeeping, tables, then the stacks on a row of their own
   const size_t lds_total = SHARED_BYTES + (scene_bytes + 255) / 256 * 256 + (size_t)depth * RENDER_THREADS * 2;
-  if (!sc.wide && lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
+  const bool keep_out = std::getenv("MIRT_NO_LDS") != nullptr;  // test aid: a small scene through the code of the large ones
+  if (!keep_out && !sc.wide && lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
     cfg.lds_scene = true;
     cfg.stack_depth = depth;
     cfg.lds_bytes = lds_total;

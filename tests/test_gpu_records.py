@@ -110,3 +110,28 @@ def test_spheres_records(scenes):
     assert set(np.unique(got["material_kind"][surf]).tolist()) == {0, 1, 2}
     inside = surf & (got["front_face"] == 0)
     assert inside.sum() > 100                                         # rays that start inside spheres
+
+
+@pytest.mark.parametrize("name,medium_type,texel_types,box,seed", [("cornel_box", None, (), ([1, 1, 1], [554, 554, 554]), 24),
+                                                                   ("final_scene", 5, (6,), ([-200, 20, -200], [600, 540, 600]), 25)])
+def test_records_of_small_scenes_walked_like_large_ones(name, medium_type, texel_types, box, seed, monkeypatch):
+    """MIRT_NO_LDS keeps a scene out of LDS: its tree is folded into four-child nodes with quantised boxes and walked
+    from global memory, its records, wrapper chains, materials and lights are read from there -- the code a scene of
+    more than 4096 primitives runs, here with every kind of primitive, wrapper, medium and texture the examples
+    have.  Same records as the oracle's, to the same bars, and a same-seed frame that matches per pixel."""
+    monkeypatch.setenv("MIRT_NO_LDS", "1")
+    g, o = R.ExampleScene(name), O.Scene(name)
+    try:
+        cam, _ = g.camera()
+        rays = np.concatenate([R.camera_rays(cam, 160, 90), random_rays(30000, box[0], box[1], seed)])
+        got, ref, surf = compare_records(g, o, rays, medium_type=medium_type, texel_types=texel_types)
+        assert surf.sum() > 20000
+        rgb, sums, st = g.render(96, 96, 4, seed=3)
+        assert not st["scene_in_lds"]
+        orgb, osums, _ = o.render(96, 96, 4, seed=3)
+        ok = np.isfinite(osums).all(axis=2) & np.isfinite(sums).all(axis=2)
+        close = np.isclose(sums, osums, rtol=1e-4, atol=1e-5).all(axis=2)
+        assert np.mean(close[ok]) > 0.97               # (a libm rounding may flip a path)
+    finally:
+        g.close()
+        o.close()
