@@ -276,22 +276,14 @@ __device__ __forceinline__ bool record_t(const SceneTables& tb, uint32_t index, 
 }
 
 // ---- conservative box test ------------------------------------------------------
-// Entry distance of the grown box, or miss (the rules and their constants: scene_device.h).  BY_RADIUS: the box
-// grows by L * (L * growth + linear), L the largest |coordinate| of the box relative to the ray origin; otherwise
-// by linear * |farthest corner|, the rule for spheres of any radius.  inv = 1/d per component.
-template <bool BY_RADIUS>
+// Entry distance of the box grown by L * (L * growth + linear), L the largest |coordinate| of the box relative to the
+// ray origin, or miss (the rule and its constants: scene_device.h).  inv = 1/d per component.
 __device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min, float t_max, float growth, float linear,
                                      float& t_near) {
   const V3 lo = bmin - o, hi = bmax - o;
-  const float mx = fmaxf(fabsf(lo.x), fabsf(hi.x)), my = fmaxf(fabsf(lo.y), fabsf(hi.y)), mz = fmaxf(fabsf(lo.z), fabsf(hi.z));
-  float pad;
-  if (BY_RADIUS) {
-    const float l = fmaxf(fmaxf(mx, my), mz);
-    pad = l * __builtin_fmaf(l, growth, linear);
-  } else {
-    // (v_sqrt_f32: one unit in the last place, part of the constant's margin)
-    pad = linear * __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx)));
-  }
+  const float l = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))),
+                        fmaxf(fabsf(lo.z), fabsf(hi.z)));
+  const float pad = l * __builtin_fmaf(l, growth, linear);
   // (lo - pad) * inv and (hi + pad) * inv, the padding folded into one fused multiply-add per plane (this
   // test only has to be conservative; its rounding is part of the padding)
   const float ex = pad * inv.x, ey = pad * inv.y, ez = pad * inv.z;
@@ -390,8 +382,8 @@ __device__ __forceinline__ void node_step(Walk& w, const SceneTables& tb, float 
   const float4* n = tb.nodes + (w.node_base + 4 * (size_t)w.cur);
   const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
   float tl, tr;
-  const bool hl = slab<true>(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, n2.w, BOX_GROW_LINEAR, tl);
-  const bool hr = slab<true>(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, n3.w, BOX_GROW_LINEAR, tr);
+  const bool hl = slab(xyz(n0), xyz(n1), w.r.o, w.inv, t_min, w.best_t, n2.w, BOX_GROW_LINEAR, tl);
+  const bool hr = slab(xyz(n2), xyz(n3), w.r.o, w.inv, t_min, w.best_t, n3.w, BOX_GROW_LINEAR, tr);
   const uint32_t left = __float_as_uint(n0.w), right = __float_as_uint(n1.w);
   if (hl && hr) {
     const bool left_first = tl <= tr;
@@ -417,20 +409,39 @@ __device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float 
   const uint32_t exps = __float_as_uint(q0.w);
   const float sx = __uint_as_float((exps & 255u) << 23), sy = __uint_as_float(((exps >> 8) & 255u) << 23),
               sz = __uint_as_float(((exps >> 16) & 255u) << 23);
+  // Per axis the plane the ray meets first is the lower one when it travels upwards and the upper one otherwise:
+  // picked once per node, on the packed bytes of the four children, this saves the per-box min / max of the two.
+  const bool up_x = !(w.inv.x < 0.0f), up_y = !(w.inv.y < 0.0f), up_z = !(w.inv.z < 0.0f);
   const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z),
                  hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
-  // lo = fma(byte, 2^e, origin): the operation the builder checked its rounding with
-#define MIRT_CHILD_BOX(k)                                                                                       \
-  v3(__builtin_fmaf(byte_of(lox, k), sx, q0.x), __builtin_fmaf(byte_of(loy, k), sy, q0.y),                       \
-     __builtin_fmaf(byte_of(loz, k), sz, q0.z)),                                                                 \
-      v3(__builtin_fmaf(byte_of(hix, k), sx, q0.x), __builtin_fmaf(byte_of(hiy, k), sy, q0.y),                   \
-         __builtin_fmaf(byte_of(hiz, k), sz, q0.z))
+  const uint32_t nx = up_x ? lox : hix, ny = up_y ? loy : hiy, nz = up_z ? loz : hiz;
+  const uint32_t fx = up_x ? hix : lox, fy = up_y ? hiy : loy, fz = up_z ? hiz : loz;
+  const float ax = fabsf(w.inv.x), ay = fabsf(w.inv.y), az = fabsf(w.inv.z);
+  // plane = fma(byte, 2^e, origin): the operation the builder checked its rounding with
+  auto child = [&](int k, float& t_near) {
+    const V3 near = v3(__builtin_fmaf(byte_of(nx, k), sx, q0.x), __builtin_fmaf(byte_of(ny, k), sy, q0.y),
+                       __builtin_fmaf(byte_of(nz, k), sz, q0.z)) - w.r.o;
+    const V3 far = v3(__builtin_fmaf(byte_of(fx, k), sx, q0.x), __builtin_fmaf(byte_of(fy, k), sy, q0.y),
+                      __builtin_fmaf(byte_of(fz, k), sz, q0.z)) - w.r.o;
+    const float mx = fmaxf(fabsf(near.x), fabsf(far.x)), my = fmaxf(fabsf(near.y), fabsf(far.y)),
+                mz = fmaxf(fabsf(near.z), fabsf(far.z));
+    // (v_sqrt_f32: one unit in the last place, part of the constant's margin)
+    const float pad = BOX_GROW_ANY * __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx)));
+    // (near - pad) / d and (far + pad) / d along the ray, the padding folded into the fused multiply-adds; a NaN
+    // (0 * inf on a plane the ray runs in) drops out of fminf / fmaxf: the axis then does not constrain
+    const float ex = pad * ax, ey = pad * ay, ez = pad * az;
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(near.x, w.inv.x, -ex), __builtin_fmaf(near.y, w.inv.y, -ey)),
+                           fmaxf(__builtin_fmaf(near.z, w.inv.z, -ez), t_min));
+    const float tf = fminf(fminf(__builtin_fmaf(far.x, w.inv.x, ex), __builtin_fmaf(far.y, w.inv.y, ey)),
+                           fminf(__builtin_fmaf(far.z, w.inv.z, ez), w.best_t));
+    t_near = tn;
+    return tn <= tf;
+  };
   float t0, t1, t2, t3;
-  const bool h0 = slab<false>(MIRT_CHILD_BOX(0), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t0) && r0 != REF_NONE;
-  const bool h1 = slab<false>(MIRT_CHILD_BOX(1), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t1) && r1 != REF_NONE;
-  const bool h2 = slab<false>(MIRT_CHILD_BOX(2), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t2) && r2 != REF_NONE;
-  const bool h3 = slab<false>(MIRT_CHILD_BOX(3), w.r.o, w.inv, t_min, w.best_t, 0.0f, BOX_GROW_ANY, t3) && r3 != REF_NONE;
-#undef MIRT_CHILD_BOX
+  const bool h0 = child(0, t0) && r0 != REF_NONE;
+  const bool h1 = child(1, t1) && r1 != REF_NONE;
+  const bool h2 = child(2, t2) && r2 != REF_NONE;
+  const bool h3 = child(3, t3) && r3 != REF_NONE;
   // entry distances are >= t_min > 0, so their bit patterns order like the numbers; a miss sorts behind every hit
   uint32_t k0 = h0 ? __float_as_uint(t0) : 0xFFFFFFFFu, k1 = h1 ? __float_as_uint(t1) : 0xFFFFFFFFu;
   uint32_t k2 = h2 ? __float_as_uint(t2) : 0xFFFFFFFFu, k3 = h3 ? __float_as_uint(t3) : 0xFFFFFFFFu;
