@@ -951,6 +951,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.save_cap = ws.save_cap;
   args.saves = ws.saves;
   args.node_min = cfg.node_min;
+  args.prims_per_turn = cfg.prims_per_turn;
   args.rays = job.rays;
   args.hit_type = job.hit_type;
   args.hit_object = job.hit_object;

@@ -287,6 +287,7 @@ struct RenderConfig {
   size_t lds_bytes;
   uint32_t refill_min;  // a wave hands in finished rays and fetches new ones once this many lanes have none
   uint32_t node_min;    // a wave keeps stepping down the tree while this many of its lanes hold an inner node
+  uint32_t prims_per_turn;  // primitive tests a lane makes, one after the other, between two runs of tree steps
 };
 RenderConfig plan_render(const DeviceScene& sc);
 // Everything the render kernel is told, read by it from device memory.
@@ -299,7 +300,7 @@ struct RenderArgs {
   RenderState* state;
   WorkCounters* work;
   float* rgb_sum;
-  uint32_t refill_min, node_min;
+  uint32_t refill_min, node_min, prims_per_turn;
   uint32_t waves_per_block;  // block size of the launch / 64; wave w of block b owns region b * waves_per_block + w
   // Scenes walked from global memory: a ray takes at most this many steps (tree steps + primitive tests) per
   // round; then its walk is put aside in `saves` (save_cap entries of SAVE_QUADS quads per region and round
