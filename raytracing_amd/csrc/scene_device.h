@@ -55,17 +55,19 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 // the reference itself never culls (aabb.rs:41-51 is always true on this path).  So every box is grown, per ray,
 // by  L * (L * growth + BOX_GROW_LINEAR),  L = the largest |coordinate| of the box relative to the ray origin:
 //  * Sphere test (objects.rs:42-56): with os = origin - centre, M = max(|os|, r) and u = 2^-24, the computed
-//    discriminant half_b^2 - a*c is off by e, |e| <= 20 u M^2 |d|^2, from |d|^2 (r^2 - m^2), m the distance of the
-//    line from the centre (17 u by first-order count: 7 u from half_b^2, 9 u from a*c, 1 u from the subtraction).
-//    Take |d| = 1.  The root the test reports is off by e_t <= 17 u M along the ray (half_b, the subtraction, the
-//    division by a), so the point P it stands for has  |P - centre|^2 = m^2 + (sqrt(disc) + e_t)^2 =
-//    r^2 + e + 2 h e_t + e_t^2 + 2 u h^2,  h <= sqrt(r^2 + e) the computed half-chord: with A = 20.1 u M^2 and
-//    B = 36 u M,  |P - centre| - r <= sqrt(r^2 + A + B r) - r.
-//      - Any radius: that is at most sqrt(A) + B / 2 = 1.094e-3 M; the rounding of origin - centre (u M) added,
-//        P lies within 1.095e-3 M of the ball.
-//      - A given radius: it is also at most (A + B r) / (2 r), so P lies within 10.05 u M^2 / r + 19 u M.
-//    Scenes staged in LDS use the second: M^2 <= 3 L^2 makes it 30.2 u L^2 / r + 33 u L, and growth =
-//    BOX_GROW_SPHERE / r = 64 u / r leaves a factor 2.1 on the quadratic part, with r the smallest sphere radius
+//    discriminant half_b^2 - a*c is off by e from |d|^2 (r^2 - m^2), m the distance of the line from the centre:
+//    half_b is off by 3 u |os| |d| (three roundings on the longest path of the dot product), so half_b^2 by
+//    6 u + 1 u; a by 3 u |d|^2 and c = |os|^2 - r^2 by 3 u + 1 u + 1 u, so a*c by 3 u + 5 u + 1 u; the subtraction
+//    adds 1 u: |e| <= 17 u M^2 |d|^2 (and terms in u^2).  Take |d| = 1.  The root the test reports is off by
+//    e_t <= 17 u M along the ray (half_b, the square root, the subtraction, a, the division), so the point P it
+//    stands for has  |P - centre|^2 = m^2 + (sqrt(disc) + e_t)^2 = r^2 + e + 2 h e_t + e_t^2 + 2 u h^2,
+//    h <= sqrt(r^2 + e) the computed half-chord: with A = 17.1 u M^2 and B = 36 u M,
+//    |P - centre| - r <= sqrt(r^2 + A + B r) - r.
+//      - Any radius: that is at most sqrt(A) + B / 2 = 1.0107e-3 M; the rounding of origin - centre (u M) added,
+//        P lies within 1.011e-3 M of the ball.
+//      - A given radius: it is also at most (A + B r) / (2 r), so P lies within 8.6 u M^2 / r + 19 u M.
+//    Scenes staged in LDS use the second: M^2 <= 3 L^2 makes it 25.7 u L^2 / r + 33 u L, and growth =
+//    BOX_GROW_SPHERE / r = 64 u / r leaves a factor 2.5 on the quadratic part, with r the smallest sphere radius
 //    below the box (a larger box has a larger L and a smaller r: its growth covers every sphere in it).
 //  * Rects and box sides (objects.rs:206-228): t = (k - o) / d and the point o + t d are off by at most
 //    4 u (|o| + L) <= 8 u L + 4 u |box|; wrapped primitives see a ray whose rotation and translation rounded by
@@ -73,14 +75,14 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 //    BOX_GROW_LINEAR = 64 u covers the parts in L (spheres 33 u + 4 u, rects 8 u + 4 u), the builder's own padding
 //    of 170 u |box| (Bounds::pad) the rest.
 // Scenes walked from global memory use the first, BOX_GROW_ANY * F, F the Euclidean length of the box's farthest
-// |coordinates| relative to the ray origin (F >= M: the box holds the ball): BOX_GROW_ANY = 1.15e-3 leaves 5 % --
+// |coordinates| relative to the ray origin (F >= M: the box holds the ball): BOX_GROW_ANY = 1.06e-3 leaves 5 % --
 // a hundred times what the box test's own rounding (4 u F), its one-instruction square root and the decoded box's
-// rounding (outwards, by the builder) take.  For rects and box sides 1.15e-3 F is far more than the 64 u L they
-// need.  (At a thousand units from a sphere of radius 0.2 the second bound would be 3 units: there the f32 test no
-// longer resolves r^2 in |os|^2 - r^2, and the first bound, 1.1 units, is what it really reports as hits.)
+// rounding (outwards, by the builder) take.  For rects and box sides 1.06e-3 F is far more than the 64 u L they
+// need.  (At a thousand units from a sphere of radius 0.2 the second bound would be 2.6 units: there the f32 test no
+// longer resolves r^2 in |os|^2 - r^2, and the first bound, 1 unit, is what it may really report as hits.)
 constexpr float BOX_GROW_SPHERE = 3.814697265625e-06f;  // 2^-18
 constexpr float BOX_GROW_LINEAR = 3.814697265625e-06f;  // 2^-18
-constexpr float BOX_GROW_ANY = 1.15e-3f;
+constexpr float BOX_GROW_ANY = 1.06e-3f;
 
 // Primitive records: 4 x float4 = one 64-byte line per primitive, in the order the tree lists them
 // (so a leaf's primitives are neighbours); boundary-only primitives follow at the end.
