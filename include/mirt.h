@@ -287,7 +287,7 @@ typedef struct mirt_render_params {
   float background[3];
   uint64_t seed;              /* Philox key */
   uint32_t path_pool;         /* paths in flight (640 bytes of device memory each); 0 = the library sizes the pool to the
-                               * call: a thirty-second of its paths, at least 8 Mi and at most 32 Mi */
+                               * call: a sixteenth of its paths, at least 8 Mi and at most 32 Mi */
   uint32_t flags;             /* MIRT_RENDER_* */
   uint32_t first_row;         /* render only rows [first_row, first_row + n_rows) of the image, row 0 = top (the */
   uint32_t n_rows;            /*   strips of renderer.rs:57-71); n_rows = 0: every row.  Buffers keep the full size. */
