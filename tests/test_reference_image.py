@@ -11,7 +11,9 @@ What is known about how it was made, from the file alone:
   blue at depth 5, 2.0 at depth 10, 0.6 from 20 on), so the frame is compared at 50;
 * the heights of the floor boxes, the cloud of small spheres and the noise texture's tables are random per run, so
   only what the scene fixes is compared: the lamp, the moving sphere, the earth, the noise sphere as a whole, the
-  scattering sphere, the small metal sphere, a patch of wall.
+  scattering sphere, the small metal sphere, a patch of wall, and the middle of the rotated cube of small spheres
+  (their places are random, their mean over the hundred or so the disc covers is not; the floor is left out: its
+  mean brightness moves by +-7 % with the seed of the box heights, the reference's lies within that spread).
 
 The lamp's outline pins Camera::new / get_ray, the row order of write_pixel and XZRect::hit to the pixel; the earth
 pins get_sphere_uv and ImageTexture's addressing; the region means pin the estimator (light sampling through the
@@ -37,7 +39,12 @@ REGIONS = {
     "scattering_sphere": (135, 366, 45),
     "metal_sphere": (425, 344, 25),
     "wall": (430, 120, 50),
+    "sphere_cluster": (320, 200, 38),   # 1000 small spheres at random places in Translate(Rotate(cube)): a mean over ~100
 }
+# what a region mean may differ by, in levels of 255 (device at 1024 spp, oracle at 6); the cluster's mean moves by
+# +-3 with the seed of its spheres' places (twelve seeds: -5.1 to +3.3 around the reference's)
+BAR = {name: (1.5, 3.0) for name in REGIONS}
+BAR["sphere_cluster"] = (6.0, 6.0)
 
 
 def reference_image():
@@ -100,7 +107,7 @@ def test_oracle_against_the_reference_frame():
         a = np.sqrt(ref_linear[m].mean(axis=0)) * 255.999
         b = np.sqrt(linear[m].mean(axis=0)) * 255.999
         channels = slice(1, 3) if name == "moving_sphere" else slice(0, 3)   # its red channel is clipped in the reference
-        assert np.abs(a - b)[channels].max() < 3.0, (name, a, b)
+        assert np.abs(a - b)[channels].max() < BAR[name][1], (name, a, b)
 
 
 @pytest.mark.gpu
@@ -119,7 +126,7 @@ def test_device_against_the_reference_frame():
     for name in REGIONS:
         m = disc(name)
         diff = np.abs(ref[m].astype(np.float64).mean(axis=0) - ours[m].astype(np.float64).mean(axis=0))
-        assert diff.max() < 1.5, (name, diff)                 # measured: at most 0.6 of 255
+        assert diff.max() < BAR[name][0], (name, diff)        # measured: at most 0.6 of 255 on what the scene fixes
     # the check can tell depths apart: at the example's max_depth of 5 the scattering sphere is 8 levels short of blue
     shallow, _, _ = g.render(SIZE, SIZE, 1024, depth=5, aspect=1.0)
     m = disc("scattering_sphere")
