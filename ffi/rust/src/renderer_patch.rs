@@ -32,13 +32,25 @@ impl Renderer {
             u: [camera.u.x, camera.u.y, camera.u.z], v: [camera.v.x, camera.v.y, camera.v.z], w: [camera.w.x, camera.w.y, camera.w.z],
             lens_radius: camera.lens_radius, time0: camera.time0, time1: camera.time1,
         };
+        // MIRT_STRIP_THREADS=t: the frame as the present code leaves it on t hardware threads (src/renderer.rs:56-71):
+        // height % t rows never rendered (black, at the end of the buffer), the image that many rows higher.
+        // Unset: every row is rendered.  C++ twin: rt::Renderer::set_strip_threads / rt::ReferenceStrips.
+        let strips: u32 = std::env::var("MIRT_STRIP_THREADS").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+        if strips > self.screen_height { return Err("more strip threads than rows".into()); }
+        let kept = if strips == 0 { self.screen_height } else { strips * (self.screen_height / strips) };
         let params = mirt_render_params {
             width: self.screen_width, height: self.screen_height, samples_per_pixel: self.samples_per_pixel,
             first_sample: 0, max_depth: self.max_depth,
             background: [self.background.x, self.background.y, self.background.z],
-            seed: rand::random(), path_pool: 0, flags: 0, first_row: 0, n_rows: 0,
+            seed: rand::random(), path_pool: 0, flags: 0,
+            first_row: self.screen_height - kept, n_rows: if strips == 0 { 0 } else { kept },
         };
         scene.render(&cam, &params, &mut self.buffer)?;
+        if kept < self.screen_height {
+            let pitch = self.screen_width as usize * 3;
+            self.buffer.copy_within(pitch * (self.screen_height - kept) as usize.., 0);
+            self.buffer[pitch * kept as usize..].fill(0);
+        }
         println!("Rendered in {}ms", now.elapsed().as_millis());
         Ok(())
     }

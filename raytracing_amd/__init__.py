@@ -260,6 +260,11 @@ def examples():
     L.rt_example_render.restype = C.c_int
     L.rt_example_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
                                     C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.POINTER(Stats)]
+    L.rt_example_render_as_reference.restype = C.c_int
+    L.rt_example_render_as_reference.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
+                                                 C.c_uint64, C.c_uint32, vp, C.POINTER(Stats)]
+    L.rt_reference_strips_place.restype = C.c_int
+    L.rt_reference_strips_place.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     L.rt_example_render_accumulate.restype = C.c_int
     L.rt_example_render_accumulate.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp,
@@ -329,6 +334,16 @@ class ExampleScene:
                                              self.depth if depth is None else depth, aspect, seed, path_pool,
                                              flags, _ptr(rgb), _ptr(sums), C.byref(st)))
         return rgb, sums, st.as_dict()
+
+    def render_as_reference(self, width, height, spp, threads, depth=None, aspect=0.0, seed=7):
+        """The frame as the reference leaves it on `threads` threads (renderer.rs:55-87): height % threads rows
+        never rendered (black, at the end), the image that many rows higher.  Returns (rgb24 HxWx3 u8, stats)."""
+        rgb = np.zeros((height, width, 3), np.uint8)
+        st = Stats()
+        self._check(self.L.rt_example_render_as_reference(self.h, width, height, spp,
+                                                          self.depth if depth is None else depth, aspect, seed,
+                                                          threads, _ptr(rgb), C.byref(st)))
+        return rgb, st.as_dict()
 
     def render_accumulate(self, sum_ptr, width, height, spp, depth=None, aspect=0.0, seed=7, first_sample=0,
                           path_pool=0, flags=0, stream=None):

@@ -197,6 +197,34 @@ int rt_example_render(void* h, uint32_t width, uint32_t height, uint32_t spp, ui
   return rc;
 }
 
+// The frame as the reference leaves it on `threads` threads (renderer.rs:55-87): the rows it renders, moved to the
+// top of the buffer, the remainder black.
+int rt_example_render_as_reference(void* h, uint32_t width, uint32_t height, uint32_t spp, uint32_t depth, float aspect,
+                                   uint64_t seed, uint32_t threads, uint8_t* rgb24, mirt_stats* stats) {
+  Example* ex = static_cast<Example*>(h);
+  const rt::ReferenceStrips strips{height, threads};
+  if (!strips.valid()) { g_error = "more strip threads than rows"; return MIRT_ERR_INVALID_ARGUMENT; }
+  mirt_camera cam;
+  float bg[3];
+  rt_example_camera(h, aspect, &cam, bg);
+  mirt_render_params p = make_params(ex, width, height, spp, 0, depth, seed, 0, 0);
+  p.first_row = strips.first_row();
+  p.n_rows = strips.rows_kept();
+  const int rc = mirt_render(ex->device.context(), ex->device.scene(), &cam, &p, rgb24, nullptr, stats);
+  if (rc != MIRT_OK) { g_error = mirt_last_error(ex->device.context()); return rc; }
+  strips.place(rgb24, width);
+  return rc;
+}
+
+// ReferenceStrips on a caller's frame (no GPU involved): moves rows [height - kept, height) to the top and blackens
+// the rest; returns the rows kept, or -1 when the reference would not run with that many threads.
+int rt_reference_strips_place(uint8_t* rgb24, uint32_t width, uint32_t height, uint32_t threads) {
+  const rt::ReferenceStrips strips{height, threads};
+  if (!strips.valid()) return -1;
+  strips.place(rgb24, width);
+  return (int)strips.rows_kept();
+}
+
 // Device-buffer render (mirt_render_accumulate) for one rank's sample range.
 int rt_example_render_accumulate(void* h, uint32_t width, uint32_t height, uint32_t spp, uint32_t first_sample,
                                  uint32_t depth, float aspect, uint64_t seed, uint32_t path_pool, uint32_t flags,

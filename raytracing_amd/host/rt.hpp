@@ -808,6 +808,22 @@ class DeviceScene {
 };
 
 // ---- renderer.rs -------------------------------------------------------------------------------------------------------
+// The frame the reference leaves when it runs on `threads` threads (renderer.rs:55-87): every thread renders
+// tile_height = height / threads rows, the buffer's first row shows scene row threads * tile_height - 1, and the
+// height % threads rows at the end of the buffer are never written.  rows_kept() of the frame's rows hold an image;
+// place() moves a frame whose rows [height - rows_kept(), height) were rendered (row 0 = top) into that layout.
+struct ReferenceStrips {
+  uint32_t height, threads;
+  bool valid() const { return threads != 0 && threads <= height; }  // (tile_height 0 panics in the reference, :67)
+  uint32_t rows_kept() const { return threads * (height / threads); }
+  uint32_t first_row() const { return height - rows_kept(); }
+  void place(uint8_t* rgb24, uint32_t width) const {
+    const size_t pitch = (size_t)width * 3;
+    std::memmove(rgb24, rgb24 + pitch * first_row(), pitch * rows_kept());
+    std::memset(rgb24 + pitch * rows_kept(), 0, pitch * first_row());
+  }
+};
+
 class Renderer {
  public:
   static Result<Renderer> create(uint32_t screen_width, uint32_t screen_height, uint32_t samples_per_pixel,
@@ -840,8 +856,15 @@ class Renderer {
     p.background[0] = background_.x; p.background[1] = background_.y; p.background[2] = background_.z;
     p.seed = seed_;
     p.flags = estimator_;
+    const ReferenceStrips strips{screen_height_, strip_threads_};
+    if (strip_threads_ != 0) {
+      if (!strips.valid()) return Status::err("more strip threads than rows");
+      p.first_row = strips.first_row();
+      p.n_rows = strips.rows_kept();
+    }
     if (mirt_render(scene.context(), scene.scene(), &cam, &p, buffer_.data(), nullptr, &stats_) != MIRT_OK)
       return Status::err(mirt_last_error(scene.context()));
+    if (strip_threads_ != 0) strips.place(buffer_.data(), screen_width_);
     const auto delta = std::chrono::steady_clock::now() - now;
     std::printf("Rendered in %lldms\n", (long long)std::chrono::duration_cast<std::chrono::milliseconds>(delta).count());
     return Status::ok();
@@ -876,6 +899,10 @@ class Renderer {
     if (!devices.empty()) devices_ = devices;
     row_bands_ = row_bands;
   }
+  // 0 (the default): every row of the frame is rendered.  t > 0: the frame as the reference leaves it on a machine
+  // with t hardware threads (renderer.rs:56-71): the height % t rows it never renders stay black at the end of the
+  // buffer and the image sits that many rows higher.
+  void set_strip_threads(uint32_t t) { strip_threads_ = t; }
   // Opt-in estimator changes (MIRT_RENDER_EVEN_LIGHTS | MIRT_RENDER_DROP_NONFINITE | MIRT_RENDER_STRATA(n)); the
   // reference has none of them, and with 0 (the default) the render is the reference's estimator.
   void set_estimator(uint32_t flags) {
@@ -891,6 +918,7 @@ class Renderer {
   mirt_stats stats_{};
   uint64_t seed_ = 7;
   uint32_t estimator_ = 0;
+  uint32_t strip_threads_ = 0;
   std::vector<int> devices_{0};
   uint32_t row_bands_ = 0;
 };

@@ -85,6 +85,26 @@ def test_reference_frame_lacks_the_remainder_rows():
     assert ref[:RENDERED_ROWS].min(axis=(1, 2)).max() > 0 and (ref[:RENDERED_ROWS].max(axis=(1, 2)) > 0).all()
 
 
+def test_host_mirror_lays_a_frame_out_as_the_reference_does():
+    """Renderer::set_strip_threads of the host mirror: rows [H % T, H) of a full frame go to the top, the rest is
+    black -- on the reference's own frame that is the identity for T = 8 and 16, and the frame says which rows."""
+    import ctypes as C
+    import raytracing_amd as R
+    place = R.examples().rt_reference_strips_place
+    ref = reference_image()
+    full = np.ascontiguousarray(np.concatenate([np.full((4, SIZE, 3), 9, np.uint8), ref[:RENDERED_ROWS]]))
+    for threads in (8, 16):
+        frame = full.copy()
+        assert place(frame.ctypes.data_as(C.c_void_p), SIZE, SIZE, threads) == RENDERED_ROWS
+        assert np.array_equal(frame, ref)
+    frame = full.copy()
+    assert place(frame.ctypes.data_as(C.c_void_p), SIZE, SIZE, 10) == SIZE and np.array_equal(frame, full)
+    assert place(frame.ctypes.data_as(C.c_void_p), SIZE, SIZE, 7) == 497            # 7 * 71
+    assert np.array_equal(frame[:497], full[3:]) and frame[497:].max() == 0
+    assert place(frame.ctypes.data_as(C.c_void_p), SIZE, SIZE, 0) == -1
+    assert place(frame.ctypes.data_as(C.c_void_p), SIZE, SIZE, 501) == -1           # tile_height 0: the reference panics
+
+
 def test_oracle_against_the_reference_frame():
     """The oracle at 6 samples per pixel (20 s): outlines to the pixel, region means on the linear sums."""
     ref = reference_image()[:RENDERED_ROWS]
@@ -127,6 +147,14 @@ def test_device_against_the_reference_frame():
         m = disc(name)
         diff = np.abs(ref[m].astype(np.float64).mean(axis=0) - ours[m].astype(np.float64).mean(axis=0))
         assert diff.max() < BAR[name][0], (name, diff)        # measured: at most 0.6 of 255 on what the scene fixes
+    # the frame laid out as the reference's 8 (or 16) strip threads leave it: comparable as it is
+    as_ref, _ = g.render_as_reference(SIZE, SIZE, 1024, 8, depth=DEPTH, aspect=1.0)
+    assert as_ref[RENDERED_ROWS:].max() == 0 and as_ref[RENDERED_ROWS - 1].max() > 0
+    whole_ref = reference_image()
+    assert int((lamp(whole_ref) ^ lamp(as_ref)).sum()) <= 30
+    assert np.abs(as_ref[:RENDERED_ROWS].astype(np.int32) - ours.astype(np.int32)).max() <= 1   # same seed, same samples
+    assert np.array_equal(g.render_as_reference(SIZE, SIZE, 4, 16, depth=DEPTH, aspect=1.0)[0][RENDERED_ROWS:],
+                          as_ref[RENDERED_ROWS:])
     # the check can tell depths apart: at the example's max_depth of 5 the scattering sphere is 8 levels short of blue
     shallow, _, _ = g.render(SIZE, SIZE, 1024, depth=5, aspect=1.0)
     m = disc("scattering_sphere")
