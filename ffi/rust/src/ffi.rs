@@ -142,4 +142,7 @@ extern "C" {
                               type_index: *mut u32, object_index: *mut u32, t: *mut f32) -> c_int;
     pub fn mirt_trace_records(ctx: *mut mirt_context, scene: *const mirt_scene, rays: *const mirt_ray, n: usize, seed: u64,
                               records: *mut mirt_hit_record) -> c_int;
+    pub fn mirt_trace_device(ctx: *mut mirt_context, scene: *const mirt_scene, rays_device: *const mirt_ray, n: usize,
+                             seed: u64, type_index_device: *mut u32, object_index_device: *mut u32, t_device: *mut f32,
+                             stream: *mut c_void) -> c_int;
 }
