@@ -1,5 +1,5 @@
 // Does a gfx950 SIMD issue a wave64 VALU instruction faster when only part of the wave's lanes are active?
-// One block of 1024 threads per CU (4 waves per SIMD); every wave runs 16 independent v_fma_f32 per turn with
+// One block of 1024, 512 or 256 threads per CU (4, 2 or 1 waves per SIMD); every wave runs 16 independent v_fma_f32 per turn with
 // the lanes of one pattern switched on.  Prints cycles per wave instruction per SIMD for each pattern.
 //
 //   hipcc -O3 --offload-arch=gfx950 -o exec_mask_probe tools/exec_mask_probe.hip && ./exec_mask_probe
@@ -45,11 +45,11 @@ __global__ void probe(float* out, unsigned long long* cycles, float seed, unsign
 int main() {
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
-  const int n_cu = prop.multiProcessorCount, threads = 1024, waves = n_cu * threads / 64;
+  const int n_cu = prop.multiProcessorCount;
   float* out;
   unsigned long long* cyc;
-  CHECK(hipMalloc(&out, (size_t)n_cu * threads * sizeof(float)));
-  CHECK(hipMalloc(&cyc, (size_t)waves * sizeof(unsigned long long)));
+  CHECK(hipMalloc(&out, (size_t)n_cu * 1024 * sizeof(float)));
+  CHECK(hipMalloc(&cyc, (size_t)n_cu * 16 * sizeof(unsigned long long)));
   struct { const char* name; unsigned long long mask; } patterns[] = {
       {"all 64 lanes", ~0ull},
       {"lanes 0-31", 0x00000000FFFFFFFFull},
@@ -58,9 +58,19 @@ int main() {
       {"lanes 0-15", 0x000000000000FFFFull},
       {"lanes 0-15 and 32-47", 0x0000FFFF0000FFFFull},
       {"lane 0", 1ull},
-      {"36 scattered lanes", 0xB6DB6DB6DB6DB6DBull & 0x0FFFFFFFFFFFFFFFull},
+      {"40 scattered lanes", 0xB6DB6DB6DB6DB6DBull & 0x0FFFFFFFFFFFFFFFull},
+      {"lanes 0-23", 0x0000000000FFFFFFull},
+      {"lanes 0-7", 0x00000000000000FFull},
+      {"lanes 0-3", 0x000000000000000Full},
+      {"every 4th lane (16)", 0x1111111111111111ull},
+      {"every 8th lane (8)", 0x0101010101010101ull},
+      {"lanes 0 and 32", 0x0000000100000001ull},
   };
+  for (int per_simd = 4; per_simd >= 1; per_simd /= 2)
   for (const auto& p : patterns) {
+    const int threads = 256 * per_simd, waves = n_cu * threads / 64;
+    if (per_simd != 4 && __builtin_popcountll(p.mask) != 64 && __builtin_popcountll(p.mask) != 16 &&
+        __builtin_popcountll(p.mask) != 8 && __builtin_popcountll(p.mask) != 1) continue;
     hipLaunchKernelGGL(probe, dim3(n_cu), dim3(threads), 0, 0, out, cyc, 1.0f, p.mask);
     CHECK(hipDeviceSynchronize());
     hipLaunchKernelGGL(probe, dim3(n_cu), dim3(threads), 0, 0, out, cyc, 1.0f, p.mask);
@@ -69,8 +79,8 @@ int main() {
     CHECK(hipMemcpy(c.data(), cyc, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long mx = 0;
     for (unsigned long long v : c) mx = v > mx ? v : mx;
-    std::printf("{\"active\": \"%s\", \"lanes\": %d, \"waves_per_simd\": 4, \"cycles_per_instruction_per_simd\": %.3f}\n", p.name,
-                __builtin_popcountll(p.mask), (double)mx / ((double)ITERS * UNROLL * 4));
+    std::printf("{\"active\": \"%s\", \"lanes\": %d, \"waves_per_simd\": %d, \"cycles_per_instruction_per_simd\": %.3f}\n", p.name,
+                __builtin_popcountll(p.mask), per_simd, (double)mx / ((double)ITERS * UNROLL * per_simd));
   }
   CHECK(hipFree(out));
   CHECK(hipFree(cyc));
