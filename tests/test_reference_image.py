@@ -11,13 +11,16 @@ What is known about how it was made, from the file alone:
   blue at depth 5, 2.0 at depth 10, 0.6 from 20 on), so the frame is compared at 50;
 * the heights of the floor boxes, the cloud of small spheres and the noise texture's tables are random per run, so
   only what the scene fixes is compared: the lamp, the moving sphere, the earth, the noise sphere as a whole, the
-  scattering sphere, the small metal sphere, a patch of wall, and the middle of the rotated cube of small spheres
+  scattering sphere, the small metal sphere, two patches of haze, and the middle of the rotated cube of small spheres
   (their places are random, their mean over the hundred or so the disc covers is not; the floor is left out: its
   mean brightness moves by +-7 % with the seed of the box heights, the reference's lies within that spread).
 
 The lamp's outline pins Camera::new / get_ray, the row order of write_pixel and XZRect::hit to the pixel; the earth
 pins get_sphere_uv and ImageTexture's addressing; the region means pin the estimator (light sampling through the
-mixture pdf, the log2 free flight of the scattering sphere, glass, fuzzed metal) as far as a converged image can.
+mixture pdf, glass, fuzzed metal) as far as a converged image can.  The haze pins the free-flight law of
+ConstantMedium (transforms.rs:154-158): the scene has no walls and a black background, so the 33 levels right of the
+sphere cube are the lamp's light scattered in by the medium that fills the scene; log2 scatters ln 2 = 0.69 times as
+often per unit length as ln would, and with ln the patch would read about 6 levels higher (the bar is 1.5).
 
 The other README image (img/img.png) shows an older scene (grey ground, sky gradient, no moving spheres) than
 examples/spheres.rs builds and is not used.
@@ -38,7 +41,8 @@ REGIONS = {
     "noise_sphere": (220, 241, 40),
     "scattering_sphere": (135, 366, 45),
     "metal_sphere": (425, 344, 25),
-    "wall": (430, 120, 50),
+    "haze": (430, 120, 50),             # no wall there: the lamp's light scattered in by the scene-wide medium
+    "dark_corner": (30, 30, 28),        # the same far from the lamp
     "sphere_cluster": (320, 200, 38),   # 1000 small spheres at random places in Translate(Rotate(cube)): a mean over ~100
 }
 # what a region mean may differ by, in levels of 255 (device at 1024 spp, oracle at 6); the cluster's mean moves by
