@@ -20,7 +20,9 @@ pins get_sphere_uv and ImageTexture's addressing; the region means pin the estim
 mixture pdf, glass, fuzzed metal) as far as a converged image can.  The haze pins the free-flight law of
 ConstantMedium (transforms.rs:154-158): the scene has no walls and a black background, so the 33 levels right of the
 sphere cube are the lamp's light scattered in by the medium that fills the scene; log2 scatters ln 2 = 0.69 times as
-often per unit length as ln would, and with ln the patch would read about 6 levels higher (the bar is 1.5).
+often per unit length as ln would, and a build of the device library with logf in that one place reads 6.4 levels
+higher there, 1.4 to 1.9 higher in the dark corner and 2.3 lower on the moving sphere (the bar is 1.5; with log2
+everything is within 0.6).
 
 The other README image (img/img.png) shows an older scene (grey ground, sky gradient, no moving spheres) than
 examples/spheres.rs builds and is not used.
