@@ -153,6 +153,11 @@ def test_device_against_the_reference_frame():
         m = disc(name)
         diff = np.abs(ref[m].astype(np.float64).mean(axis=0) - ours[m].astype(np.float64).mean(axis=0))
         assert diff.max() < BAR[name][0], (name, diff)        # measured: at most 0.6 of 255 on what the scene fixes
+    # the marble of the noise sphere: its tables are random per run, the contrast of the pattern is not (perlin.rs
+    # turbulence, texture.rs:67-80).  Twelve scene seeds: 50.8 to 51.4 against the reference's 51.0
+    m = disc("noise_sphere")
+    contrast = [im[m].astype(np.float64).mean(axis=1).std() for im in (ref, ours)]
+    assert abs(contrast[0] - contrast[1]) < 1.5, contrast
     # the frame laid out as the reference's 8 (or 16) strip threads leave it: comparable as it is
     as_ref, _ = g.render_as_reference(SIZE, SIZE, 1024, 8, depth=DEPTH, aspect=1.0)
     assert as_ref[RENDERED_ROWS:].max() == 0 and as_ref[RENDERED_ROWS - 1].max() > 0
