@@ -35,9 +35,10 @@ typedef struct mirt_scene mirt_scene;
 enum {
   MIRT_OK = 0,
   MIRT_ERR_INVALID_ARGUMENT = 1,
-  MIRT_ERR_DEVICE = 2,       /* a HIP call failed; see mirt_last_error */
+  MIRT_ERR_DEVICE = 2,       /* a HIP call failed, or the host side could not go on (a thread per device could not be
+                              * started, an exception other than out-of-memory was caught); see mirt_last_error */
   MIRT_ERR_UNSUPPORTED = 3,  /* scene uses a construct the device path does not lower */
-  MIRT_ERR_OUT_OF_MEMORY = 4
+  MIRT_ERR_OUT_OF_MEMORY = 4 /* device memory, or host memory (std::bad_alloc caught at the entry point) */
 };
 
 /* ---- primitives (object-space parameters) -------------------------------- */

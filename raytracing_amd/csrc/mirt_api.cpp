@@ -12,6 +12,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -95,6 +96,54 @@ int fail(mirt_context* ctx, int code, const std::string& msg) {
   if (ctx) ctx->error = msg;
   else g_create_error = msg;
   return code;
+}
+
+// No exception leaves the library (the callers are C and Rust): every entry point that allocates host memory or
+// starts threads is a function-try-block that ends here.
+int caught(mirt_context* ctx) noexcept {
+  int code = MIRT_ERR_DEVICE;
+  const char* what = "unexpected exception";
+  std::string text;
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    code = MIRT_ERR_OUT_OF_MEMORY;
+    what = "out of host memory";
+  } catch (const std::exception& e) {
+    try { text = e.what(); what = text.c_str(); } catch (...) {}
+  } catch (...) {
+  }
+  try { (void)fail(ctx, code, what); } catch (...) {}
+  return code;
+}
+
+// job(0) on the calling thread, job(1) .. job(n - 1) on a thread each; returns when all of them have.  A job that
+// throws leaves an error code in status[k].  False when a thread could not be started: the jobs already started
+// have still run to their end, job(0) has not.
+template <class Job>
+bool side_by_side(size_t n, const Job& job, std::vector<int>& status) {
+  auto guarded = [&](size_t k) {
+    try {
+      job(k);
+    } catch (const std::bad_alloc&) {
+      status[k] = MIRT_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+      status[k] = MIRT_ERR_DEVICE;
+    }
+  };
+  std::vector<std::thread> workers;
+  workers.reserve(n);  // (if this throws, no thread exists yet)
+  bool started = true;
+  for (size_t k = 1; k < n && started; ++k) {
+    try {
+      workers.emplace_back(guarded, k);
+    } catch (const std::system_error&) {
+      started = false;
+    }
+  }
+  if (started) guarded(0);
+  for (std::thread& w : workers) w.join();
+  return started;
 }
 
 #define MIRT_HIP(ctx, call)                                                                      \
@@ -252,7 +301,7 @@ int mirt_version(void) { return 100; }
 
 const char* mirt_last_error(const mirt_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
-int mirt_context_create_multi(const int* device_ids, int n_devices, uint32_t row_bands, mirt_context** out) {
+int mirt_context_create_multi(const int* device_ids, int n_devices, uint32_t row_bands, mirt_context** out) try {
   if (!out) return fail(nullptr, MIRT_ERR_INVALID_ARGUMENT, "out is null");
   *out = nullptr;
   if (!device_ids || n_devices < 1 || n_devices > 64)
@@ -290,11 +339,13 @@ int mirt_context_create_multi(const int* device_ids, int n_devices, uint32_t row
   (void)hipSetDevice(first->device);
   *out = first;
   return MIRT_OK;
+} catch (...) {
+  return caught(nullptr);
 }
 
 int mirt_context_device_count(const mirt_context* ctx) { return ctx ? 1 + (int)ctx->others.size() : 0; }
 
-int mirt_context_create(int device_id, mirt_context** out) {
+int mirt_context_create(int device_id, mirt_context** out) try {
   if (!out) return fail(nullptr, MIRT_ERR_INVALID_ARGUMENT, "out is null");
   *out = nullptr;
   int count = 0;
@@ -325,6 +376,8 @@ int mirt_context_create(int device_id, mirt_context** out) {
   }
   *out = ctx;
   return MIRT_OK;
+} catch (...) {
+  return caught(nullptr);
 }
 
 void mirt_context_destroy(mirt_context* ctx) {
@@ -350,22 +403,22 @@ void mirt_scene_destroy(mirt_context* ctx, mirt_scene* scene) {
 
 static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene** out);
 
-int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene** out) {
+int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene** out) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!desc || !out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
   // every device of the context gets its own copy, built side by side (one host thread per device)
   const size_t n_others = ctx->others.size();
   std::vector<mirt_scene*> copies(n_others, nullptr);
-  std::vector<int> status(n_others, MIRT_OK);
-  std::vector<std::thread> workers;
-  for (size_t k = 0; k < n_others; ++k)
-    workers.emplace_back([&, k] { status[k] = upload_one(ctx->others[k], desc, &copies[k]); });
+  std::vector<int> status(1 + n_others, MIRT_OK);  // [0]: this context's own device
   mirt_scene* first = nullptr;
-  int rc = upload_one(ctx, desc, &first);
-  for (std::thread& w : workers) w.join();
+  const bool started = side_by_side(1 + n_others, [&](size_t k) {
+    status[k] = k == 0 ? upload_one(ctx, desc, &first) : upload_one(ctx->others[k - 1], desc, &copies[k - 1]);
+  }, status);
+  int rc = started ? status[0] : fail(ctx, MIRT_ERR_DEVICE, "cannot start a host thread per device");
   for (size_t k = 0; k < n_others && rc == MIRT_OK; ++k)
-    if (status[k] != MIRT_OK) rc = fail(ctx, status[k], "device " + std::to_string(ctx->others[k]->device) + ": " + ctx->others[k]->error);
+    if (status[k + 1] != MIRT_OK)
+      rc = fail(ctx, status[k + 1], "device " + std::to_string(ctx->others[k]->device) + ": " + ctx->others[k]->error);
   if (rc != MIRT_OK) {
     for (size_t k = 0; k < n_others; ++k) {
       (void)hipSetDevice(ctx->others[k]->device);
@@ -379,6 +432,8 @@ int mirt_scene_upload(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   (void)hipSetDevice(ctx->device);
   *out = first;
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
 static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene** out) {
@@ -1135,11 +1190,9 @@ int render_shared(mirt_context* ctx, const mirt_scene* scene, const mirt_camera*
   };
   for (size_t k = 1; k < n; ++k)
     MIRT_HIP(ctx, ctx->staging[k - 1]->ensure(std::max<size_t>(16, row_values * shares[k].n_rows * sizeof(float))));
-  std::vector<std::thread> workers;
-  for (size_t k = 1; k < n; ++k) workers.emplace_back(work, k);
-  work(0);
-  for (std::thread& w : workers) w.join();
+  const bool started = side_by_side(n, work, status);
   MIRT_HIP(ctx, hipSetDevice(ctx->device));
+  if (!started) return fail(ctx, MIRT_ERR_DEVICE, "cannot start a host thread per device");
   for (size_t k = 0; k < n; ++k)
     if (status[k] != MIRT_OK) {
       if (k != 0) ctx->error = "device " + std::to_string(ctx->others[k - 1]->device) + ": " + ctx->others[k - 1]->error;
@@ -1176,24 +1229,28 @@ int render_shared(mirt_context* ctx, const mirt_scene* scene, const mirt_camera*
 extern "C" {
 
 int mirt_render_accumulate(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
-                           const mirt_render_params* params, float* rgb_sum_device, void* stream, mirt_stats* stats) {
+                           const mirt_render_params* params, float* rgb_sum_device, void* stream, mirt_stats* stats) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   return render_impl(ctx, scene, camera, params, rgb_sum_device, (hipStream_t)stream /* NULL: the null stream */, stats);
+} catch (...) {
+  return caught(ctx);
 }
 
 int mirt_render_accumulate_static(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
                                   const mirt_render_params* params, float* rgb_sum_device, void* stream,
-                                  mirt_stats* stats) {
+                                  mirt_stats* stats) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (params && (params->flags & MIRT_RENDER_TIME_KERNELS))
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "MIRT_RENDER_TIME_KERNELS creates events: not available without allocation");
   return render_impl(ctx, scene, camera, params, rgb_sum_device, (hipStream_t)stream /* NULL: the null stream */, stats, true);
+} catch (...) {
+  return caught(ctx);
 }
 
 int mirt_static_workspace_paths(void) { return (int)STATIC_POOL_PATHS; }
 
 int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width, uint32_t height,
-                 uint32_t samples_per_pixel, uint8_t* rgb24_device, void* stream) {
+                 uint32_t samples_per_pixel, uint8_t* rgb24_device, void* stream) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!rgb_sum_device || !rgb24_device || width == 0 || height == 0 || samples_per_pixel == 0)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "bad resolve argument");
@@ -1204,10 +1261,12 @@ int mirt_resolve(mirt_context* ctx, const float* rgb_sum_device, uint32_t width,
   MIRT_HIP(ctx, hipGetLastError());
   MIRT_HIP(ctx, hipStreamSynchronize(s));
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
 int mirt_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
-                const mirt_render_params* params, uint8_t* rgb24_out, float* rgb_sum_out, mirt_stats* stats) {
+                const mirt_render_params* params, uint8_t* rgb24_out, float* rgb_sum_out, mirt_stats* stats) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!params) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   if ((uint64_t)params->width * params->height >= (1ull << 30)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "image too large");
@@ -1231,6 +1290,8 @@ int mirt_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
                                  ctx->stream));
   MIRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
 }  // extern "C"
@@ -1247,7 +1308,7 @@ struct mirt_frame {
 
 extern "C" {
 
-int mirt_frame_create(mirt_context* ctx, uint32_t width, uint32_t height, mirt_frame** out) {
+int mirt_frame_create(mirt_context* ctx, uint32_t width, uint32_t height, mirt_frame** out) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
@@ -1266,6 +1327,8 @@ int mirt_frame_create(mirt_context* ctx, uint32_t width, uint32_t height, mirt_f
   }
   *out = f;
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
 void mirt_frame_destroy(mirt_context* ctx, mirt_frame* frame) {
@@ -1276,7 +1339,7 @@ void mirt_frame_destroy(mirt_context* ctx, mirt_frame* frame) {
 uint32_t mirt_frame_samples(const mirt_frame* frame) { return frame ? frame->samples : 0; }
 
 int mirt_frame_render(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
-                      const mirt_render_params* params, mirt_frame* frame, mirt_stats* stats) {
+                      const mirt_render_params* params, mirt_frame* frame, mirt_stats* stats) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!scene || !camera || !params || !frame) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   if (params->width != frame->width || params->height != frame->height)
@@ -1315,9 +1378,11 @@ int mirt_frame_render(mirt_context* ctx, const mirt_scene* scene, const mirt_cam
   frame->flags = estimator;
   frame->samples += params->samples_per_pixel;
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
-int mirt_frame_read(mirt_context* ctx, const mirt_frame* frame, uint8_t* rgb24_out, float* rgb_sum_out) {
+int mirt_frame_read(mirt_context* ctx, const mirt_frame* frame, uint8_t* rgb24_out, float* rgb_sum_out) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!frame) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   MIRT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1336,9 +1401,11 @@ int mirt_frame_read(mirt_context* ctx, const mirt_frame* frame, uint8_t* rgb24_o
     MIRT_HIP(ctx, hipMemcpyAsync(rgb_sum_out, frame->sums.ptr, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   MIRT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
-int mirt_frame_save(mirt_context* ctx, const mirt_frame* frame, const char* path) {
+int mirt_frame_save(mirt_context* ctx, const mirt_frame* frame, const char* path) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!frame || !path) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   std::vector<float> host(frame->values());
@@ -1358,9 +1425,11 @@ int mirt_frame_save(mirt_context* ctx, const mirt_frame* frame, const char* path
             std::fwrite(host.data(), sizeof(float), host.size(), f) == host.size();
   ok = (std::fclose(f) == 0) && ok;
   return ok ? MIRT_OK : fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string("short write on ") + path);
+} catch (...) {
+  return caught(ctx);
 }
 
-int mirt_frame_load(mirt_context* ctx, const char* path, mirt_frame** out) {
+int mirt_frame_load(mirt_context* ctx, const char* path, mirt_frame** out) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!path || !out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
@@ -1407,6 +1476,8 @@ int mirt_frame_load(mirt_context* ctx, const char* path, mirt_frame** out) {
   frame->started = has_started ? started != 0 : n != 0;
   *out = frame;
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
 static int trace_device_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays_device, size_t n,
@@ -1433,9 +1504,11 @@ static int trace_device_impl(mirt_context* ctx, const mirt_scene* scene, const m
 }
 
 int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays_device, size_t n, uint64_t seed,
-                      uint32_t* type_index_device, uint32_t* object_index_device, float* t_device, void* stream) {
+                      uint32_t* type_index_device, uint32_t* object_index_device, float* t_device, void* stream) try {
   return trace_device_impl(ctx, scene, rays_device, n, seed, type_index_device, object_index_device, t_device, nullptr,
                            stream);
+} catch (...) {
+  return caught(ctx);
 }
 
 static int check_ray_times(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n) {
@@ -1447,7 +1520,7 @@ static int check_ray_times(mirt_context* ctx, const mirt_scene* scene, const mir
 }
 
 int mirt_trace_records(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,
-                       mirt_hit_record* records) {
+                       mirt_hit_record* records) try {
   static_assert(sizeof(mirt_hit_record) == 64, "a hit record is four quads");
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!scene || (n && (!rays || !records))) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
@@ -1467,10 +1540,12 @@ int mirt_trace_records(mirt_context* ctx, const mirt_scene* scene, const mirt_ra
   if (rc != MIRT_OK) return rc;
   MIRT_HIP(ctx, hipMemcpy(records, d_rec.ptr, n * sizeof(mirt_hit_record), hipMemcpyDeviceToHost));
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
 int mirt_trace_primary(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays, size_t n, uint64_t seed,
-                       uint32_t* type_index, uint32_t* object_index, float* t) {
+                       uint32_t* type_index, uint32_t* object_index, float* t) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   if (!scene || (n && (!rays || !type_index || !object_index || !t)))
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "null argument");
@@ -1491,6 +1566,8 @@ int mirt_trace_primary(mirt_context* ctx, const mirt_scene* scene, const mirt_ra
   MIRT_HIP(ctx, hipMemcpy(object_index, d_oi.ptr, n * 4, hipMemcpyDeviceToHost));
   MIRT_HIP(ctx, hipMemcpy(t, d_t.ptr, n * 4, hipMemcpyDeviceToHost));
   return MIRT_OK;
+} catch (...) {
+  return caught(ctx);
 }
 
 }  // extern "C"
