@@ -313,16 +313,21 @@ int mirt_context_create_multi(const int* device_ids, int n_devices, uint32_t row
   int rc = mirt_context_create(device_ids[0], &first);
   if (rc != MIRT_OK) return rc;
   first->row_bands = row_bands;
+  struct Owner {  // the contexts made so far are this function's until the whole set is handed out
+    mirt_context* ctx;
+    ~Owner() { if (ctx) mirt_context_destroy(ctx); }
+  } owner{first};
+  first->others.reserve((size_t)n_devices);
+  first->staging.reserve((size_t)n_devices);
   for (int k = 1; k < n_devices; ++k) {
+    first->staging.push_back(new DeviceBuffer());  // (room reserved: only the allocation can throw, and nothing is half-owned then)
     mirt_context* other = nullptr;
     rc = mirt_context_create(device_ids[k], &other);
     if (rc != MIRT_OK) {
       const std::string why = g_create_error;
-      mirt_context_destroy(first);
       return fail(nullptr, rc, "device " + std::to_string(device_ids[k]) + ": " + why);
     }
     first->others.push_back(other);
-    first->staging.push_back(new DeviceBuffer());
     if (other->device != first->device) {
       // direct copies over the GPUs' links where the platform allows them (already enabled is fine; without peer
       // access hipMemcpyPeer still works, through the host)
@@ -337,6 +342,7 @@ int mirt_context_create_multi(const int* device_ids, int n_devices, uint32_t row
     }
   }
   (void)hipSetDevice(first->device);
+  owner.ctx = nullptr;
   *out = first;
   return MIRT_OK;
 } catch (...) {
@@ -1458,22 +1464,23 @@ int mirt_frame_load(mirt_context* ctx, const char* path, mirt_frame** out) try {
   mirt_frame* frame = nullptr;
   const int rc = mirt_frame_create(ctx, (uint32_t)w, (uint32_t)h, &frame);
   if (rc != MIRT_OK) return rc;
+  struct Owner {  // the frame is this function's until it is handed out
+    mirt_context* ctx;
+    mirt_frame* frame;
+    ~Owner() { if (frame) mirt_frame_destroy(ctx, frame); }
+  } owner{ctx, frame};
   std::vector<float> host(frame->values());
   char extra;
-  if (std::fread(host.data(), sizeof(float), host.size(), f) != host.size() || std::fread(&extra, 1, 1, f) != 0) {
-    mirt_frame_destroy(ctx, frame);
+  if (std::fread(host.data(), sizeof(float), host.size(), f) != host.size() || std::fread(&extra, 1, 1, f) != 0)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, std::string(path) + ": truncated checkpoint");
-  }
   const hipError_t e = hipMemcpy(frame->sums.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    mirt_frame_destroy(ctx, frame);
-    return fail(ctx, MIRT_ERR_DEVICE, hipGetErrorString(e));
-  }
+  if (e != hipSuccess) return fail(ctx, MIRT_ERR_DEVICE, hipGetErrorString(e));
   frame->samples = (uint32_t)n;
   frame->seed = seed;
   frame->max_depth = (uint32_t)depth;
   frame->flags = (uint32_t)flags;
   frame->started = has_started ? started != 0 : n != 0;
+  owner.frame = nullptr;
   *out = frame;
   return MIRT_OK;
 } catch (...) {
