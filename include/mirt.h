@@ -440,7 +440,9 @@ int mirt_trace_records(mirt_context* ctx, const mirt_scene* scene, const mirt_ra
                        mirt_hit_record* records);
 
 /* Device-resident variant used for timing the traversal alone: rays is a
- * device array of n mirt_ray, outputs are device arrays of n. */
+ * device array of n mirt_ray, outputs are device arrays of n.  The rays' times are not checked here (the host
+ * variants reject a time outside the scene's [time0, time1]): such a ray may miss a moving sphere, whose box only
+ * covers that interval. */
 int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray* rays_device, size_t n,
                       uint64_t seed, uint32_t* type_index_device, uint32_t* object_index_device, float* t_device,
                       void* stream);
