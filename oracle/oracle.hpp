@@ -10,7 +10,7 @@
 // layout) and its Rust toolchain is absent here, so no ray, record or sample
 // of this restatement has been compared bit for bit with the reference
 // running.  What it is checked against: the 500x500 render of the final scene
-// in the reference's README (img/img2.png, a copy under tests/golden/): the
+// in the reference's README (img/img2.png, its pixels under tests/golden/): the
 // lamp's outline to the pixel (6 of 14 141 pixels differ), the textured and
 // the moving sphere at 46 to 48 dB, the mean colour of every part of the
 // frame the scene fixes within 0.6 of 255 (tests/test_reference_image.py);

@@ -1,6 +1,6 @@
 """The one output of this path that the reference itself holds: the render of the final scene its README shows
-(/root/reference/img/img2.png, README.md; copied as data to tests/golden/reference_final_scene_500x500.png,
-sha256 61321e04...8c41b1).  It is a 500x500 frame of examples/final_scene.rs' scene and camera (aspect 1).
+(/root/reference/img/img2.png, README.md; its pixels, decoded by tools/decode_reference_image.py, are
+tests/golden/reference_final_scene_500x500.npz; sha256 of the PNG 61321e04...8c41b1).  It is a 500x500 frame of examples/final_scene.rs' scene and camera (aspect 1).
 
 What is known about how it was made, from the file alone:
 * its last 4 rows are black and everything else sits 4 rows higher than a full 500-row render: Renderer::render
@@ -34,7 +34,7 @@ import pytest
 
 import oracle_lib as O
 
-GOLDEN = Path(__file__).resolve().parent / "golden" / "reference_final_scene_500x500.png"
+GOLDEN = Path(__file__).resolve().parent / "golden" / "reference_final_scene_500x500.npz"
 SIZE, RENDERED_ROWS, DEPTH = 500, 496, 50
 # discs (centre x, centre y, radius) in the reference image's own pixel coordinates, well inside each object
 REGIONS = {
@@ -54,8 +54,7 @@ BAR["sphere_cluster"] = (6.0, 6.0)
 
 
 def reference_image():
-    from PIL import Image
-    return np.asarray(Image.open(GOLDEN).convert("RGB"))
+    return np.load(GOLDEN)["rgb"]
 
 
 def as_reference_rows(frame):
