@@ -27,6 +27,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# RCCL shares buffers between the ranks of a node through dmabuf handles, the only kind the host driver here
+# supports; the legacy IPC mode fails with "hipIpcGetMemHandle: invalid argument".  (Set before HIP loads.)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, spec
 VALU_PEAK_TFLOPS = 157.3    # MI355X FP32 vector, spec
