@@ -22,7 +22,8 @@ ConstantMedium (transforms.rs:154-158): the scene has no walls and a black backg
 sphere cube are the lamp's light scattered in by the medium that fills the scene; log2 scatters ln 2 = 0.69 times as
 often per unit length as ln would, and a build of the device library with logf in that one place reads 6.4 levels
 higher there, 1.4 to 1.9 higher in the dark corner and 2.3 lower on the moving sphere (the bar is 1.5; with log2
-everything is within 0.6).
+everything is within 0.6).  Likewise Metal, which never absorbs in the reference (material.rs:75-91): a build that
+ends a fuzzed reflection pointing into the surface reads 5 levels darker on the metal sphere.
 
 The other README image (img/img.png) shows an older scene (grey ground, sky gradient, no moving spheres) than
 examples/spheres.rs builds and is not used.
