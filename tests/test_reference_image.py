@@ -23,7 +23,10 @@ sphere cube are the lamp's light scattered in by the medium that fills the scene
 often per unit length as ln would, and a build of the device library with logf in that one place reads 6.4 levels
 higher there, 1.4 to 1.9 higher in the dark corner and 2.3 lower on the moving sphere (the bar is 1.5; with log2
 everything is within 0.6).  Likewise Metal, which never absorbs in the reference (material.rs:75-91): a build that
-ends a fuzzed reflection pointing into the surface reads 5 levels darker on the metal sphere.
+ends a fuzzed reflection pointing into the surface reads 5 levels darker on the metal sphere.  And the medium's hit
+normal, (1,0,0) for every ray (transforms.rs:160-172), under a Lambertian phase material: the haze is lit only where
+the lamp lies towards +x, 33 levels in the patch on the right against 6 in the left corner; a build with (-1,0,0)
+reads 9 and 38.
 
 The other README image (img/img.png) shows an older scene (grey ground, sky gradient, no moving spheres) than
 examples/spheres.rs builds and is not used.
