@@ -297,7 +297,7 @@ int validate_desc(const mirt_scene_desc& d, std::string& why) {
 
 extern "C" {
 
-int mirt_version(void) { return 100; }
+int mirt_version(void) { return 200; }  // 0.2.0: contexts over several GPUs, frames, hit records, the fixed workspace
 
 const char* mirt_last_error(const mirt_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
