@@ -139,6 +139,78 @@ def test_oracle_against_the_reference_frame():
         assert np.abs(a - b)[channels].max() < BAR[name][1], (name, a, b)
 
 
+ORACLE_FRAME = Path(__file__).resolve().parent / "golden" / "oracle_final_scene_500x500.npz"
+
+
+def halved(mask):
+    """A pixel mask of the 496 rendered rows as a mask of the 2x2 blocks that lie wholly inside it."""
+    return mask.reshape(RENDERED_ROWS // 2, 2, SIZE // 2, 2).all(axis=(1, 3))
+
+
+def test_oracle_fixture_against_the_reference_frame():
+    """The oracle alone, held to the bars a converged frame allows: its own render of the README frame at 128
+    samples per pixel and max_depth 50 (tests/golden/oracle_final_scene_500x500.npz, made by
+    `tools/make_goldens.py reference_frame` in 10 minutes on 6 threads) against the reference's pixels.  The lamp's
+    outline to the pixel, region means within 1.5 levels on the linear sums (the reference's 8-bit values squared
+    back; the sphere cluster, random per run, within 6), the earth at > 40 dB on 4x4 block means of the linear sums
+    and the moving sphere at > 40 dB on 8x8 block means of the encoded frame (its red channel is clipped in the
+    reference, so it is compared after encoding).  Measured: 11 lamp pixels, 1.2 levels, 41.1 and 46.8 dB."""
+    fx = np.load(ORACLE_FRAME)
+    assert (int(fx["width"]), int(fx["height"]), int(fx["depth"]), int(fx["spp"])) == (SIZE, SIZE, DEPTH, 128)
+    ref = reference_image()[:RENDERED_ROWS]
+    ours = as_reference_rows(fx["rgb"])
+    mismatch = int((lamp(ref) ^ lamp(ours)).sum())
+    assert mismatch <= 60, mismatch
+    for shift in (-1, 1):                           # one row off: 400 pixels more
+        moved = fx["rgb"][SIZE - RENDERED_ROWS + shift:][:RENDERED_ROWS]
+        assert int((lamp(ref) ^ lamp(moved)).sum()) > mismatch + 300
+    # linear radiance per 2x2 block (rows 4.. of the full frame are the reference's rows 0..495; 4 is even)
+    ours_lin = (fx["linear_2x2_sum"].astype(np.float64) / np.maximum(fx["finite_2x2"], 1)[:, :, None])[(SIZE - RENDERED_ROWS) // 2:]
+    ref_lin = ((ref.astype(np.float64) / 255.999) ** 2).reshape(RENDERED_ROWS // 2, 2, SIZE // 2, 2, 3).mean(axis=(1, 3))
+    worst = {}
+    for name in REGIONS:
+        m = halved(disc(name))
+        a = np.sqrt(ref_lin[m].mean(axis=0)) * 255.999
+        b = np.sqrt(ours_lin[m].mean(axis=0)) * 255.999
+        channels = slice(1, 3) if name == "moving_sphere" else slice(0, 3)
+        worst[name] = float(np.abs(a - b)[channels].max())
+        assert worst[name] < BAR[name][0], (name, a, b)
+    # the earth: 4x4 pixel blocks of linear radiance, encoded
+    inside = block_means(halved(disc("earth"))[:, :, None].astype(np.float64), 2)[:, :, 0] == 1.0
+    x = np.sqrt(block_means(ref_lin, 2)[inside]) * 255.999
+    y = np.sqrt(block_means(ours_lin, 2)[inside]) * 255.999
+    earth = 10.0 * np.log10(255.0 ** 2 / np.mean((x - y) ** 2))
+    assert earth > 40.0 and np.corrcoef(x.ravel(), y.ravel())[0, 1] > 0.999, earth
+    psnr, corr = block_psnr(ref, ours, "moving_sphere", 8)
+    assert psnr > 40.0 and corr > 0.999, (psnr, corr)
+    # the marble's contrast (tables random per run): 51.0 in the reference, 52.0 here at 128 spp (noise adds a little)
+    m = disc("noise_sphere")
+    contrast = [im[m].astype(np.float64).mean(axis=1).std() for im in (ref, ours)]
+    assert abs(contrast[0] - contrast[1]) < 2.0, contrast
+    # and the check tells depths apart: at the example's present max_depth of 5 the oracle's scattering sphere is
+    # short of the reference's blue by several levels (32 spp, region means only)
+    names = [str(n) for n in fx["depth5_regions"]]
+    shallow = np.sqrt(fx["depth5_region_means"][names.index("scattering_sphere")]) * 255.999
+    m = disc("scattering_sphere")
+    deep = np.sqrt(((ref.astype(np.float64) / 255.999) ** 2)[m].mean(axis=0)) * 255.999
+    assert deep[2] - shallow[2] > 5.0, (deep, shallow)
+
+
+def test_oracle_fixture_is_the_present_oracle():
+    """The fixture was rendered by the oracle as it stands: a fresh render of a strip of the frame with the
+    fixture's seed gives the same region mean within sampling noise (and a changed rule would show in the region
+    tests above only after the fixture is made again: this ties the two together)."""
+    fx = np.load(ORACLE_FRAME)
+    spp = 4
+    _, sums, _ = O.Scene("final_scene").render(SIZE, SIZE, spp, depth=DEPTH, aspect=1.0, seed=int(fx["seed"]))
+    linear = np.nan_to_num(as_reference_rows(sums).astype(np.float64) / spp, nan=0.0, posinf=0.0)
+    ours_lin = (fx["linear_2x2_sum"].astype(np.float64) / np.maximum(fx["finite_2x2"], 1)[:, :, None])[(SIZE - RENDERED_ROWS) // 2:]
+    for name in ("earth", "noise_sphere", "haze", "metal_sphere"):
+        a = np.sqrt(linear[disc(name)].mean(axis=0)) * 255.999
+        b = np.sqrt(ours_lin[halved(disc(name))].mean(axis=0)) * 255.999
+        assert np.abs(a - b).max() < 3.0, (name, a, b)
+
+
 @pytest.mark.gpu
 def test_device_against_the_reference_frame():
     """The device library through the C ABI at 1024 samples per pixel: the same checks on the encoded frame,

@@ -46,7 +46,50 @@ BLOCKS = {  # name: (scene, width, height, spp per pixel, block edge)
 }
 
 
+# the oracle's own render of the frame the reference's README shows (img/img2.png: final_scene, 500x500, aspect 1;
+# max_depth 50, see tests/test_reference_image.py): the encoded frame and the linear per-pixel sums as f16-safe f32
+REFERENCE_FRAME = ("final_scene", 500, 500, 128, 50)
+
 what = sys.argv[1:] or ["primary"] + list(CONVERGED)
+if "reference_frame" in what:
+    scene, w, h, spp, depth = REFERENCE_FRAME
+    t0 = time.time()
+    s = O.Scene(scene, scene_seed=1)
+    threads = int(__import__("os").environ.get("GOLDEN_THREADS", "0")) or max(1, len(__import__("os").sched_getaffinity(0)) - 1)
+    part = Path("/tmp") / "make_goldens_reference_frame.npz"
+    sums, seg, done = np.zeros((h, w, 3), np.float64), 0, 0
+    if part.exists():
+        z = np.load(part)
+        if (int(z["width"]), int(z["height"]), int(z["seed"]), int(z["depth"])) == (w, h, SEED, depth):
+            sums, seg, done = z["sums"], int(z["segments"]), int(z["done"])
+    while done < spp:
+        n = min(8, spp - done)
+        _, pass_sums, pass_seg = s.render(w, h, n, depth=depth, aspect=1.0, seed=SEED, first_sample=done, threads=threads)
+        sums += pass_sums
+        seg += pass_seg
+        done += n
+        np.savez(part, sums=sums, segments=seg, done=done, width=w, height=h, seed=SEED, depth=depth)
+        print("reference_frame", done, "of", spp, "spp", round(time.time() - t0, 1), "s", flush=True)
+    sums32 = sums.astype(np.float32)
+    rgb = O.encode(sums32, spp)
+    # linear means over 2x2 pixels (finite pixels only) keep the fixture small and are all the region checks need
+    finite = np.isfinite(sums32).all(axis=2)
+    lin = np.where(finite[:, :, None], sums32 / spp, 0.0).reshape(h // 2, 2, w // 2, 2, 3).sum(axis=(1, 3))
+    cnt = finite.reshape(h // 2, 2, w // 2, 2).sum(axis=(1, 3))
+    # the same frame at the example's present max_depth of 5 (examples/final_scene.rs:8), 32 spp: only the mean linear
+    # radiance of the regions tests/test_reference_image.py compares (the frame itself is not kept)
+    import test_reference_image as T  # noqa: E402
+    shallow_spp = 32
+    _, shallow, _ = s.render(w, h, shallow_spp, depth=5, aspect=1.0, seed=SEED, threads=threads)
+    shallow = np.nan_to_num(T.as_reference_rows(shallow).astype(np.float64) / shallow_spp, nan=0.0, posinf=0.0)
+    names = sorted(T.REGIONS)
+    shallow_means = np.array([shallow[T.disc(n)].mean(axis=0) for n in names])
+    print("reference_frame depth 5", round(time.time() - t0, 1), "s", flush=True)
+    np.savez_compressed(GOLD / "oracle_final_scene_500x500.npz", rgb=rgb, linear_2x2_sum=lin.astype(np.float32),
+                        finite_2x2=cnt.astype(np.uint8), width=w, height=h, spp=spp, depth=depth, seed=SEED,
+                        scene_seed=1, aspect=np.float32(1.0), segments_per_sample=np.float64(seg / (w * h * spp)),
+                        depth5_regions=np.array(names), depth5_region_means=shallow_means, depth5_spp=shallow_spp)
+    print("reference_frame", w, h, spp, round(time.time() - t0, 1), "s", flush=True)
 for name, (scene, w, h, spp, block) in BLOCKS.items():
     if name not in what:
         continue
