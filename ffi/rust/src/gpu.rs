@@ -15,9 +15,18 @@ fn create_error() -> String {
     unsafe { CStr::from_ptr(mirt_last_error(ptr::null())).to_string_lossy().into_owned() }
 }
 
+/// The structs of ffi.rs mirror include/mirt.h at this version and carry no size field: an older library
+/// would read and write past them.
+const HEADER_VERSION: i32 = 200;
+fn check_version() -> Result<(), String> {
+    let v = unsafe { mirt_version() };
+    if v >= HEADER_VERSION { Ok(()) } else { Err(format!("libmirt {} is older than the bindings ({})", v, HEADER_VERSION)) }
+}
+
 impl Context {
     /// One GPU.
     pub fn new(device: i32) -> Result<Self, String> {
+        check_version()?;
         let mut raw = ptr::null_mut();
         if unsafe { mirt_context_create(device, &mut raw) } != MIRT_OK { return Err(create_error()); }
         Ok(Self { raw })
@@ -25,6 +34,7 @@ impl Context {
     /// Several GPUs of the node: the frame is shared out between them as the reference shares it out between
     /// threads (src/renderer.rs:55-87).  `row_bands` = 0: sample ranges only.
     pub fn over(devices: &[i32], row_bands: u32) -> Result<Self, String> {
+        check_version()?;
         let mut raw = ptr::null_mut();
         if unsafe { mirt_context_create_multi(devices.as_ptr(), devices.len() as i32, row_bands, &mut raw) } != MIRT_OK {
             return Err(create_error());

@@ -385,15 +385,18 @@ int mirt_render_accumulate(mirt_context* ctx, const mirt_scene* scene, const mir
                            const mirt_render_params* params, float* rgb_sum_device, void* stream,
                            mirt_stats* stats);
 
-/* mirt_render_accumulate for callers that may not allocate device memory (code under HIP graph capture, serving
- * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The path pool, the counters
+/* mirt_render_accumulate for callers that may not allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc).  It has no counterpart in the reference.  It is a blocking call like the others (it copies its
+ * launch arguments to the device and waits for the stream), so it cannot be recorded into a HIP graph.  The path pool, the counters
  * and the launch arguments live in a fixed workspace the library holds on every GPU (46 MiB: 65 536 paths of 640
  * bytes, a control page, and room for walks put aside); the call
  * makes no hipMalloc / hipFree and creates no events, so MIRT_RENDER_TIME_KERNELS is rejected.  The workspace holds
  * mirt_static_workspace_paths() paths in flight: params->path_pool = 0 uses all of them, a larger path_pool is
  * rejected with MIRT_ERR_INVALID_ARGUMENT (images of any size are rendered through the pool; the small pool makes
- * this entry point slower than mirt_render_accumulate).  All calls on one GPU share its workspace: two such
- * calls that overlap on one GPU race, whatever their contexts and streams. */
+ * this entry point slower than mirt_render_accumulate).  All calls on one GPU share its workspace, whatever
+ * their contexts and streams: a call made while another one is still running on the same GPU (from another thread)
+ * is rejected with MIRT_ERR_INVALID_ARGUMENT, and calls from several processes on one GPU each have a workspace of
+ * their own. */
 int mirt_render_accumulate_static(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* camera,
                                   const mirt_render_params* params, float* rgb_sum_device, void* stream,
                                   mirt_stats* stats);
@@ -447,7 +450,13 @@ int mirt_trace_device(mirt_context* ctx, const mirt_scene* scene, const mirt_ray
                       uint64_t seed, uint32_t* type_index_device, uint32_t* object_index_device, float* t_device,
                       void* stream);
 
-/* Library version: major*10000 + minor*100 + patch. */
+/* Library version: major*10000 + minor*100 + patch.  The structs of this header carry no size field: a caller
+ * must be built against the header of the library it loads and should check mirt_version() >= MIRT_HEADER_VERSION
+ * once after loading.  Changes that a caller built against an older header would not survive:
+ *   0.2.0  mirt_render_params grew by first_row / n_rows, mirt_stats by scene_in_lds / lds_bytes; a NULL `stream`
+ *          in mirt_render_accumulate, mirt_resolve and mirt_trace_device means the null stream (it was the
+ *          context's own stream before), which does not order against the caller's non-blocking streams. */
+#define MIRT_HEADER_VERSION 200
 int mirt_version(void);
 
 #ifdef __cplusplus

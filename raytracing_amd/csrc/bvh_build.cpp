@@ -304,10 +304,11 @@ std::vector<QuantNode> quantize_wide(const WideBvh& wide) {
       // the smallest power-of-two spacing with 255 steps reaching the far side; one more when rounding gets in the way
       int e = 0;
       (void)std::frexp(std::max((mx - mn) / 255.0f, std::numeric_limits<float>::min()), &e);  // 2^(e-1) <= x < 2^e
+      bool ok = true;
       for (;; ++e) {
         if (e < -125) e = -125;
         const float step = std::ldexp(1.0f, e);
-        bool ok = true;
+        ok = true;
         for (int c = 0; c < 4 && ok; ++c) {
           if (w.child[c] == 0xFFFFFFFFu) { q.lo[a][c] = 255; q.hi[a][c] = 0; continue; }
           float lo = std::floor((w.lo[a][c] - mn) / step);
@@ -322,6 +323,9 @@ std::vector<QuantNode> quantize_wide(const WideBvh& wide) {
         }
         if (ok || e >= 127) break;
       }
+      if (!ok)  // (bounds near the largest f32: no spacing fits; the whole grid then stands for every child)
+        for (int c = 0; c < 4; ++c)
+          if (w.child[c] != 0xFFFFFFFFu) { q.lo[a][c] = 0; q.hi[a][c] = 255; }
       q.exps |= (uint32_t)(e + 127) << (8 * a);  // the bits of 2^e are (e + 127) << 23
     }
   }

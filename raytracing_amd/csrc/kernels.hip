@@ -934,6 +934,23 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_idx) {  // 
 // ---- wave helpers ---------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
+// Diagnostic build (-DMIRT_CHECKED, `make CHECKED=1`): every index the render kernel computes into global memory is
+// tested before use.  The first violation is recorded in WorkCounters::check (site, three values, region) and the
+// access is skipped, so a bad index shows up as a message from the host (run_job) instead of a memory fault.
+// In the normal build the test is the constant `true` and leaves no code behind.
+#ifdef MIRT_CHECKED
+__device__ __noinline__ void check_failed(WorkCounters* wc, uint32_t site, uint32_t a, uint32_t b, uint32_t c) {
+  if (atomicCAS(&wc->check[0], 0ull, (unsigned long long)site) == 0ull) {
+    wc->check[1] = a; wc->check[2] = b; wc->check[3] = c;
+    wc->check[4] = blockIdx.x; wc->check[5] = threadIdx.x;
+  }
+  atomicAdd(&wc->check[6], 1ull);
+}
+#define MIRT_CHECK(ok, wc, site, a, b, c) ((ok) ? true : (check_failed((wc), (site), (uint32_t)(a), (uint32_t)(b), (uint32_t)(c)), false))
+#else
+#define MIRT_CHECK(ok, wc, site, a, b, c) true
+#endif
+
 // Reserves one slot per lane that passes `pred` with a single atomic per wave.
 __device__ __forceinline__ uint32_t wave_reserve(bool pred, uint32_t* counter) {
   const unsigned long long mask = __ballot(pred);
@@ -1207,6 +1224,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   for (int k = 0; k < 3; ++k) ahead[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   auto read_ahead = [&](uint32_t first) {
     const uint32_t e = min(first + lane, max(n_stored, 1u) - 1u);
+    if (!MIRT_CHECK(e < cap, A->work, 1, e, cap, n_stored)) return;
     ahead[0] = cur[e]; ahead[1] = cur[(size_t)cap + e]; ahead[2] = cur[2 * (size_t)cap + e];
   };
   if (AHEAD) read_ahead(0u);
@@ -1284,10 +1302,12 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
         // the whole path record moves into the queue, hit included: shading reads its queue front to back
         float4* const out = region_queues + 4 * (size_t)q * cap + pos;
+        if (MIRT_CHECK(pos < cap && q < N_QUEUES, A->work, 2, pos, cap, q)) {
         out[0] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, w.r.time);
         out[cap] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, pixel_bits);
         out[2 * (size_t)cap] = state;
         out[3 * (size_t)cap] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), __uint_as_float(saved_at));
+        }
         slot = NO_SLOT;
         w.cur = RC::NONE;
         if (LDS_SCENE || q != QUEUE_CONTINUE) ++segments;
@@ -1302,7 +1322,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         if (slot == NO_SLOT && entry < total) {
           slot = entry;
           if (entry >= n_stored) camera.start(entry - n_stored, r0, r1, r2);
-          else if (!AHEAD) { r0 = cur[slot]; r1 = cur[(size_t)cap + slot]; r2 = cur[2 * (size_t)cap + slot]; }
+          else if (!AHEAD && MIRT_CHECK(slot < cap, A->work, 3, slot, cap, n_stored)) { r0 = cur[slot]; r1 = cur[(size_t)cap + slot]; r2 = cur[2 * (size_t)cap + slot]; }
           state = r2;
           pixel_bits = r1.w;
           Ray r;
@@ -1517,12 +1537,13 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       V3 beta = v3(0.0f, 0.0f, 0.0f);
       uint32_t pixel = 0, sample = 0, bounce = 0;
       uint32_t saved_walk = 0;  // 1 + entry of the save area for a ray whose walk was put aside
-      if (e < n_q) {
+      if (e < n_q && MIRT_CHECK(from + e < cap, A->work, 5, e, from, n_q)) {
         const float4* const rec = entries + e;
         const float4 r0 = rec[0], r1 = rec[cap], r2 = rec[2 * (size_t)cap], r3 = rec[3 * (size_t)cap];
         Ray r;
         r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
         pixel = __float_as_uint(r1.w);
+        if (!MIRT_CHECK(pixel < rc.width * rc.height, A->work, 7, pixel, q, e)) pixel = 0;
         beta = xyz(r2);
         sample = __float_as_uint(r2.w) >> 8;
         bounce = __float_as_uint(r2.w) & 255u;
@@ -1541,8 +1562,10 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
               deferred = true;
               const uint32_t at = sh.queue_n[to_q] + atomicAdd(&sh.late_n[to_q], 1u);
               float4* const out = region_queues + 4 * (size_t)to_q * cap + at;
+              if (MIRT_CHECK(at < cap && to_q < (uint32_t)N_QUEUES, A->work, 6, at, cap, to_q)) {
               out[0] = r0; out[cap] = r1; out[2 * (size_t)cap] = r2;
               out[3 * (size_t)cap] = make_float4(t, __uint_as_float(ref), r3.z, r3.w);
+              }
             }
           }
         }
@@ -1557,9 +1580,15 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
           beta = v3(0.0f, 0.0f, 0.0f);  // nothing to add to the image from here
         } else if (ref == REF_NONE) {
           term = v3(rc.background[0], rc.background[1], rc.background[2]);  // renderer.rs:187-189
+        } else if (!MIRT_CHECK((ref & REF_LEAF) && (ref_tag(ref) == TAG_MEDIUM ? ref_index(ref) < n_media
+                                                                              : ref_tag(ref) <= TAG_BOX && ref_index(ref) < A->sc.n_prims),
+                               A->work, 9, ref, q, e)) {
+          beta = v3(0.0f, 0.0f, 0.0f);
         } else {
           const Hit h = hit_record<PSTRIDE>(tb, block.media, ref, r, t, __float_as_uint(r3.z));
-          const DMaterial m = sc.materials[h.material_word & 0x0FFFFFFFu];
+          uint32_t material_index = h.material_word & 0x0FFFFFFFu;
+          if (!MIRT_CHECK(material_index < A->sc.n_materials, A->work, 10, h.material_word, ref, q)) material_index = 0;
+          const DMaterial m = sc.materials[material_index];
           Rng rng = rng_begin(pixel, sample, bounce, STAGE_SHADE, rc.key0, rc.key1);
           // the one texture lookup of the materials that have one (a light's only shows on its front side)
           V3 att = v3(0.0f, 0.0f, 0.0f);
@@ -1623,7 +1652,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       }
       // survivors are packed into the first slots of the region's other buffer
       const size_t to = wave_reserve(alive, &sh.n_next);
-      if (alive) {
+      if (alive && MIRT_CHECK(to < cap, A->work, 8, to, cap, q)) {
         next[to] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
         next[cap + to] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
         next[2 * (size_t)cap + to] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
@@ -1831,6 +1860,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     const uint32_t n_fresh = uniform(sh.n_fresh);
     const uint32_t total = n_surv + n_fresh;
     if (total == 0) break;  // nothing alive and nothing left to start: the region is done
+    if (!MIRT_CHECK(total <= pinned(args)->rc.region_cap, pinned(args)->work, 11, n_surv, n_fresh, rounds)) break;
     const bool odd = (rounds & 1u) != 0;  // the region's two buffers swap roles every round
     ++rounds;
 
@@ -1960,8 +1990,8 @@ RenderConfig plan_render(const DeviceScene& sc) {
   // staged scenes are small enough for 16-bit tree references, so a stack entry is 2 bytes;
   // bookkeeping, tables, then the stacks on a row of their own
   const size_t lds_total = SHARED_BYTES + (scene_bytes + 255) / 256 * 256 + (size_t)depth * RENDER_THREADS * 2;
-  const bool keep_out = std::getenv("MIRT_NO_LDS") != nullptr;  // test aid: a small scene through the code of the large ones
-  if (!keep_out && !sc.wide && lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
+  // (sc.keep_out: the test aid MIRT_NO_LDS, read once when the scene is uploaded -- the node layout depends on it)
+  if (!sc.keep_out && !sc.wide && lds_total <= LDS_BYTES_PER_CU && sc.n_prims <= COMPACT_MAX_PRIMS && sc.n_nodes < COMPACT_MAX_NODES) {
     cfg.lds_scene = true;
     cfg.stack_depth = depth;
     cfg.lds_bytes = lds_total;

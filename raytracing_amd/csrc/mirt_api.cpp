@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -333,11 +334,18 @@ int mirt_context_create_multi(const int* device_ids, int n_devices, uint32_t row
       // access hipMemcpyPeer still works, through the host)
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, first->device, other->device) == hipSuccess && can) {
-        (void)hipSetDevice(first->device);
-        (void)hipDeviceEnablePeerAccess(other->device, 0);
-        (void)hipSetDevice(other->device);
-        (void)hipDeviceEnablePeerAccess(first->device, 0);
-        (void)hipGetLastError();
+        // (hipErrorPeerAccessAlreadyEnabled is as good as success; any other failure only means the copies go
+        // through the host, which MIRT_VERBOSE reports)
+        auto enable = [](int on, int peer) {
+          (void)hipSetDevice(on);
+          const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+          (void)hipGetLastError();
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled && std::getenv("MIRT_VERBOSE"))
+            std::fprintf(stderr, "mirt: no peer access from device %d to %d (%s): copies go through the host\n", on, peer,
+                         hipGetErrorString(e));
+        };
+        enable(first->device, other->device);
+        enable(other->device, first->device);
       }
     }
   }
@@ -570,6 +578,8 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   // fewer tree steps, 4-10 % fewer primitive tests, and 1-11 % fewer samples per second -- the copies share neither
   // cache lines nor LDS -- so one copy is the default and more are an experiment (MIRT_TIME_SLICES).
   uint32_t n_slices = 1;
+  // test aid, read here once for the scene's lifetime: keeps a small scene out of LDS (four-child nodes, global tables)
+  const uint32_t keep_out = std::getenv("MIRT_NO_LDS") != nullptr ? 1u : 0u;
   if (s.has_moving && d.time1 > d.time0) {
     if (const char* e = std::getenv("MIRT_TIME_SLICES")) {
       const long v = std::strtol(e, nullptr, 10);
@@ -608,6 +618,7 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
       probe.n_textures = d.n_textures;
       probe.n_lights = d.n_lights;
       probe.n_light_groups = d.n_light_groups;
+      probe.keep_out = keep_out;
       return plan_render(probe).lds_scene;
     };
     const bool retry = !std::getenv("MIRT_NO_LDS_RETRY");  // measurement aid
@@ -672,6 +683,7 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
     probe.n_textures = d.n_textures;
     probe.n_lights = d.n_lights;
     probe.n_light_groups = d.n_light_groups;
+    probe.keep_out = keep_out;
     wide = !plan_render(probe).lds_scene && n_nodes != 0;
   }
   if (wide) {
@@ -822,6 +834,7 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   v.slice_time0 = d.time0;
   v.slice_scale = n_slices > 1 ? (float)n_slices / (d.time1 - d.time0) : 0.0f;
   v.wide = wide ? 1u : 0u;
+  v.keep_out = keep_out;
   v.bvh_height = s.bvh_height;
   v.n_chains = d.n_chains;
   v.prims = s.prims.as<float4>();
@@ -930,9 +943,6 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
                                         : std::min<uint64_t>(std::max<uint64_t>(total / 16, 1u << 23), 1u << 25);
   want = std::min<uint64_t>(want, total);
   want = std::min<uint64_t>(std::max<uint64_t>(want, granule), 1u << 27);
-  const uint32_t pool = (uint32_t)((want + granule - 1) / granule * granule);
-  job.rc.pool = pool;
-  job.rc.region_cap = pool / regions;
 
   // Large scenes (from 2^18 primitives): a ray takes at most `budget` steps per round; longer walks are put aside
   // and go on in the next round, so the few rays that graze such a scene for thousands of steps no longer hold up
@@ -947,24 +957,44 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   }
 
   Workspace ws;
+  uint32_t pool = 0;
   if (job.fixed_workspace) {
+    pool = (uint32_t)((want + granule - 1) / granule * granule);
     if (pool > STATIC_POOL_PATHS) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "pool beyond the fixed workspace");
     if (!ctx->static_workspace) return fail(ctx, MIRT_ERR_DEVICE, "the fixed workspace of this device was not found");
     ws = carve_static_workspace(ctx->static_workspace);
   } else {
-    MIRT_HIP(ctx, ctx->paths[0].ensure((size_t)pool * 64));
-    MIRT_HIP(ctx, ctx->paths[1].ensure((size_t)pool * 64));
-    MIRT_HIP(ctx, ctx->queues.ensure((size_t)pool * 64 * N_QUEUES));
     MIRT_HIP(ctx, ctx->state.ensure(sizeof(RenderState)));
     MIRT_HIP(ctx, ctx->work.ensure(sizeof(WorkCounters)));
     MIRT_HIP(ctx, ctx->args.ensure(sizeof(RenderArgs)));
-    // (the save area is only there for walks with a step budget)
-    const uint32_t save_cap = step_budget ? std::max(64u, job.rc.region_cap / 4) : 0u;
-    MIRT_HIP(ctx, ctx->saves.ensure(std::max<size_t>(256, (size_t)2 * regions * save_cap * SAVE_QUADS * 16)));
-    ws = Workspace{{ctx->paths[0].as<float4>(), ctx->paths[1].as<float4>()}, ctx->queues.as<float4>(),
-                   ctx->state.as<RenderState>(), ctx->work.as<WorkCounters>(), ctx->args.as<RenderArgs>(),
-                   ctx->saves.as<uint4>(), save_cap};
+    // The pool is 640 bytes a path (5 to 21 GB at the default sizes) plus, with a step budget, 96 bytes a path of
+    // save area.  When the device cannot give that much -- other contexts, other processes -- the pool is halved,
+    // down to one wave's worth per region, before the call gives up: a smaller pool is slower, not wrong.
+    for (;;) {
+      pool = (uint32_t)((want + granule - 1) / granule * granule);
+      // (the save area is only there for walks with a step budget; sized from the pool actually asked for)
+      const uint32_t save_cap = step_budget ? std::max(64u, pool / regions / 4) : 0u;
+      hipError_t e = ctx->paths[0].ensure((size_t)pool * 64);
+      if (e == hipSuccess) e = ctx->paths[1].ensure((size_t)pool * 64);
+      if (e == hipSuccess) e = ctx->queues.ensure((size_t)pool * 64 * N_QUEUES);
+      if (e == hipSuccess) e = ctx->saves.ensure(std::max<size_t>(256, (size_t)2 * regions * save_cap * SAVE_QUADS * 16));
+      if (e == hipSuccess) {
+        ws = Workspace{{ctx->paths[0].as<float4>(), ctx->paths[1].as<float4>()}, ctx->queues.as<float4>(),
+                       ctx->state.as<RenderState>(), ctx->work.as<WorkCounters>(), ctx->args.as<RenderArgs>(),
+                       ctx->saves.as<uint4>(), save_cap};
+        break;
+      }
+      (void)hipGetLastError();  // (the failed allocation's sticky error)
+      ctx->paths[0].release(); ctx->paths[1].release(); ctx->queues.release(); ctx->saves.release();
+      if (e != hipErrorOutOfMemory || pool <= granule || job.want_pool != 0)
+        return fail(ctx, e == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_DEVICE,
+                    std::string("path pool of ") + std::to_string(pool) + " paths: " + hipGetErrorString(e));
+      want = std::max<uint64_t>(granule, pool / 2);
+      if (std::getenv("MIRT_VERBOSE")) std::fprintf(stderr, "mirt: out of device memory at %u paths, trying %llu\n", pool, (unsigned long long)want);
+    }
   }
+  job.rc.pool = pool;
+  job.rc.region_cap = pool / regions;
   // (the workspace keeps the last call's contents: the counters must start at zero, the rest is written before read)
   MIRT_HIP(ctx, hipMemsetAsync(ws.state, 0, sizeof(RenderState), stream));
   MIRT_HIP(ctx, hipMemsetAsync(ws.work, 0, sizeof(WorkCounters), stream));
@@ -976,6 +1006,10 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
                  scene->n_prims, scene->view.n_nodes, scene->view.bvh_height,
                  cfg.lds_scene ? "scene in LDS" : "scene in global memory", cfg.grid, cfg.block, cfg.lds_bytes,
                  cfg.stack_depth, pool);
+  if (std::getenv("MIRT_VERBOSE"))
+    std::fprintf(stderr, "mirt: paths %p %p (%zu B each), queues %p (%zu B), saves %p, state %p, work %p, args %p, image %p\n",
+                 (void*)ws.paths[0], (void*)ws.paths[1], (size_t)pool * 64, (void*)ws.queues, (size_t)pool * 64 * N_QUEUES,
+                 (void*)ws.saves, (void*)ws.state, (void*)ws.work, (void*)ws.args, (void*)job.rgb_sum);
 
   hipEvent_t ev[2] = {nullptr, nullptr};
   struct EventGuard {
@@ -1024,6 +1058,19 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   if (time_kernels) MIRT_HIP(ctx, hipEventRecord(ev[1], stream));
   MIRT_HIP(ctx, hipStreamSynchronize(stream));
   const auto t_end = std::chrono::steady_clock::now();
+#ifdef MIRT_CHECKED
+  {  // diagnostic build: an index the kernel found out of range ends the call with what it recorded
+    WorkCounters w{};
+    MIRT_HIP(ctx, hipMemcpy(&w, ws.work, sizeof(w), hipMemcpyDeviceToHost));
+    if (w.check[0] != 0) {
+      char msg[256];
+      std::snprintf(msg, sizeof(msg), "index check %llu failed (%llu times): values %llu %llu %llu, block %llu thread %llu",
+                    w.check[0], w.check[6], w.check[1], w.check[2], w.check[3], w.check[4], w.check[5]);
+      std::fprintf(stderr, "mirt: %s\n", msg);
+      return fail(ctx, MIRT_ERR_DEVICE, msg);
+    }
+  }
+#endif
   if (stats) {
     stats->render_ms = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
     stats->path_pool = pool;
@@ -1107,6 +1154,17 @@ int render_impl(mirt_context* ctx, const mirt_scene* scene, const mirt_camera* c
   job.want_pool = p.path_pool;
   job.flags = p.flags;
   job.fixed_workspace = fixed_workspace;
+  if (!fixed_workspace) return run_job(ctx, scene, job, stream, stats);
+  // Every call on a GPU works in that GPU's one fixed workspace: a call made while another one is still running
+  // there (from another thread; the calls block) is turned away instead of racing with it.
+  static std::atomic<bool> busy[64];
+  std::atomic<bool>& flag = busy[(unsigned)ctx->device & 63u];
+  if (flag.exchange(true, std::memory_order_acquire))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "the fixed workspace of this GPU is in use by another call");
+  struct Release {
+    std::atomic<bool>& f;
+    ~Release() { f.store(false, std::memory_order_release); }
+  } release{flag};
   return run_job(ctx, scene, job, stream, stats);
 }
 
@@ -1190,8 +1248,11 @@ int render_shared(mirt_context* ctx, const mirt_scene* scene, const mirt_camera*
     if (status[k] != MIRT_OK || k == 0) return;
     // the share's rows, to the first device (the staging buffer was sized before the threads started)
     const size_t bytes = row_values * sh.n_rows * sizeof(float);
-    if (!hip_ok(hipMemcpyPeer(ctx->staging[k - 1]->ptr, ctx->device, sums + row_values * sh.first_row, c->device, bytes),
-                "hipMemcpyPeer")) return;
+    // (on this device's own stream, behind its render, and waited for here: the add on the first device starts only
+    // after every worker thread has returned, so no ordering between streams of different devices is relied on)
+    if (!hip_ok(hipMemcpyPeerAsync(ctx->staging[k - 1]->ptr, ctx->device, sums + row_values * sh.first_row, c->device, bytes,
+                                   c->stream), "hipMemcpyPeerAsync")) return;
+    if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize after the peer copy")) return;
     copied[k] = 1;
   };
   for (size_t k = 1; k < n; ++k)

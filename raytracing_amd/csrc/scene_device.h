@@ -147,6 +147,7 @@ struct DeviceScene {
   uint32_t n_slices;
   float slice_time0, slice_scale;
   uint32_t wide;  // nodes are four-child WideNodes (the scene is walked from global memory)
+  uint32_t keep_out;  // never staged in LDS, whatever its size (MIRT_NO_LDS at upload: a small scene through the large scenes' code)
 
   const float4* prims;  // primitive records, layout above
   const uint2* prim_ids;
@@ -198,6 +199,9 @@ struct WorkCounters {
   // shader-clock cycles summed over waves, per phase of the render kernel (instrumented build only):
   // 0 start paths + fetch rays, 1 tree steps, 2 primitive tests, 3 shade, 4 hand-in + binning, 5 whole kernel
   unsigned long long cycles[MIRT_PHASE_COUNT];
+  // diagnostic build (MIRT_CHECKED) only: site of the first index found out of range (0 = none), the three values
+  // recorded there, block and thread that found it, number of violations in all
+  unsigned long long check[8];
 };
 
 // Hits are shaded queue by queue so that a wave runs one material's code: Lambertian surfaces of one colour,

@@ -59,3 +59,62 @@ def test_static_workspace_rejects_what_it_cannot_hold():
     rc, msg, img, st = _render(L.mirt_render_accumulate_static, g, 64, 64, 1, pool=limit)
     assert rc == 0 and st["path_pool"] <= limit, msg
     g.close()
+
+
+def test_static_workspace_call_leaves_device_memory_alone():
+    """No hipMalloc / hipFree inside the call: the device's free memory reads the same before and after (the
+    allocating entry point, called first on a fresh pool size, does move it)."""
+    L = R.mirt()
+    g = R.ExampleScene("final_scene")
+    rc, msg, _, _ = _render(L.mirt_render_accumulate_static, g, 64, 36, 1)      # first use on this device done
+    assert rc == 0, msg
+    cam, bg = g.camera(16 / 9)
+    p = R.RenderParams(320, 180, 4, 0, g.depth, (C.c_float * 3)(*bg), 11, 0, 0)
+    sums = torch.zeros((180, 320, 3), dtype=torch.float32, device="cuda:0")
+    st = R.Stats()
+    ctx, scene = g.L.rt_example_context(g.h), g.L.rt_example_scene(g.h)
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info(0)
+    rc = L.mirt_render_accumulate_static(ctx, scene, C.byref(cam), C.byref(p), C.c_void_p(sums.data_ptr()), None, C.byref(st))
+    free_after, _ = torch.cuda.mem_get_info(0)
+    assert rc == 0, L.mirt_last_error(ctx).decode()
+    assert free_after == free_before, (free_before, free_after)
+    assert float(sums.sum()) > 0
+    g.close()
+
+
+def test_static_workspace_turns_an_overlapping_call_away():
+    """Two calls at once on one GPU would share the workspace: the second is rejected, not raced."""
+    import threading
+    L = R.mirt()
+    a, b = R.ExampleScene("final_scene"), R.ExampleScene("cornel_box")     # two contexts, one GPU
+    result = {}
+
+    def long_call():
+        result["a"] = _render(L.mirt_render_accumulate_static, a, 1920, 1080, 16)
+
+    # (the second caller's buffers are made beforehand: nothing in its loop waits for the device)
+    cam, bg = b.camera(1.0)
+    p = R.RenderParams(32, 32, 1, 0, b.depth, (C.c_float * 3)(*bg), 11, 0, 0)
+    sums = torch.zeros((32, 32, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx, scene = b.L.rt_example_context(b.h), b.L.rt_example_scene(b.h)
+    t = threading.Thread(target=long_call)
+    t.start()
+    rejected, accepted = 0, 0
+    while t.is_alive():
+        rc = L.mirt_render_accumulate_static(ctx, scene, C.byref(cam), C.byref(p), C.c_void_p(sums.data_ptr()), None, None)
+        if rc == 1 and "in use" in L.mirt_last_error(ctx).decode():
+            rejected += 1
+        else:
+            assert rc == 0, L.mirt_last_error(ctx).decode()
+            accepted += 1
+    t.join()
+    rc, msg, img, _ = result["a"]
+    assert rc == 0, msg
+    assert np.isfinite(img[np.isfinite(img)]).all() and np.nanmax(img) > 0
+    assert rejected > 0, (rejected, accepted)
+    rc, msg, _, _ = _render(L.mirt_render_accumulate_static, b, 32, 32, 1)    # and free again afterwards
+    assert rc == 0, msg
+    a.close()
+    b.close()
