@@ -1075,6 +1075,139 @@ struct BVH final : Hittable {
 };
 
 // ---------------------------------------------------------------------------
+// NOT in the reference: a flattened BVH with a box test that culls.
+//
+// The reference's containers test every object against every ray (world.rs:75-94 scans, bvh.rs:92-145 visits both
+// children of every node because aabb.rs:41-51 is always true): hours per frame at ten million spheres.  This
+// container is the CPU baseline for such scenes and a fast checker for them: the objects, their hit tests and the
+// tie rule are the World's own (closest hit, an equal t to the object later in the World's scan order, as
+// World::hit's shrinking t_max gives), only the objects whose grown box the ray misses are skipped.  A box is grown
+// by 1.06e-3 of the distance from the ray origin to its farthest corner before the test: the f32 sphere test of
+// objects.rs:42-56 reports hits up to 1.011e-3 of that distance off the sphere, so no object the scan would have
+// accepted is skipped (tests/test_oracle_kat.py holds it to the scan, ids and t bits, on the same rays).
+// ---------------------------------------------------------------------------
+struct CulledBVH final : Hittable {
+  struct Node {
+    float lo[3], hi[3];
+    uint32_t left, right;  // inner: children; leaf: left = first entry of `order` | LEAF, right = count
+  };
+  static constexpr uint32_t LEAF = 0x80000000u;
+  World world;
+  std::vector<Node> nodes;
+  std::vector<WorldIndex> order;  // leaves point into this
+  uint32_t root = 0;
+
+  static CulledBVH from_world(World w) {
+    CulledBVH b;
+    b.world = std::move(w);
+    auto volumes = b.world.volumes();
+    std::vector<uint32_t> idx(volumes.size());
+    for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
+    b.order.reserve(volumes.size());
+    b.nodes.reserve(volumes.size() / 2 + 1);
+    b.root = b.build(volumes, idx.data(), idx.size());
+    return b;
+  }
+  uint32_t build(const std::vector<std::pair<WorldIndex, AABB>>& v, uint32_t* idx, size_t n) {
+    Node nd;
+    float clo[3], chi[3];
+    for (int a = 0; a < 3; ++a) { nd.lo[a] = clo[a] = INF_F; nd.hi[a] = chi[a] = -INF_F; }
+    auto comp = [](const Vec3& p, int a) { return a == 0 ? p.x : (a == 1 ? p.y : p.z); };
+    for (size_t i = 0; i < n; ++i) {
+      const AABB& b = v[idx[i]].second;
+      for (int a = 0; a < 3; ++a) {
+        const float l = comp(b.minimum, a), h = comp(b.maximum, a), c = 0.5f * (l + h);
+        nd.lo[a] = std::min(nd.lo[a], l); nd.hi[a] = std::max(nd.hi[a], h);
+        clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c);
+      }
+    }
+    int axis = 0;
+    if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+    if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+    if (n <= 4 || !(chi[axis] > clo[axis])) {
+      nd.left = LEAF | (uint32_t)order.size();
+      nd.right = (uint32_t)n;
+      for (size_t i = 0; i < n; ++i) order.push_back(v[idx[i]].first);
+      nodes.push_back(nd);
+      return (uint32_t)nodes.size() - 1;
+    }
+    const size_t half = n / 2;
+    std::nth_element(idx, idx + half, idx + n, [&](uint32_t a, uint32_t b) {
+      const AABB &x = v[a].second, &y = v[b].second;
+      return comp(x.minimum, axis) + comp(x.maximum, axis) < comp(y.minimum, axis) + comp(y.maximum, axis);
+    });
+    const uint32_t l = build(v, idx, half), r = build(v, idx + half, n - half);
+    nd.left = l; nd.right = r;
+    nodes.push_back(nd);
+    return (uint32_t)nodes.size() - 1;
+  }
+  // entry distance into the grown box, or false when the ray misses it within [t_min, t_max]
+  static bool grown_box(const Node& nd, const Ray& ray, const float inv[3], float t_min, float t_max, float& t_near) {
+    const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
+    float lo[3], hi[3], f2 = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = nd.lo[a] - o[a]; hi[a] = nd.hi[a] - o[a];
+      const float m = std::fmax(std::fabs(lo[a]), std::fabs(hi[a]));
+      f2 += m * m;
+    }
+    const float pad = 1.06e-3f * std::sqrt(f2);
+    float tn = t_min, tf = t_max;
+    for (int a = 0; a < 3; ++a) {
+      const float t0 = (lo[a] - pad) * inv[a], t1 = (hi[a] + pad) * inv[a];
+      // fmin / fmax drop a NaN (0 * inf: the ray runs in a face's plane): the axis then does not constrain
+      tn = std::fmax(tn, std::fmin(t0, t1));
+      tf = std::fmin(tf, std::fmax(t0, t1));
+    }
+    t_near = tn;
+    return tn <= tf * 1.0000004f + 1e-30f;
+  }
+  bool hit_indexed(const Ray& ray, float t_min, float t_max, HitRecord& out, WorldIndex& who) const {
+    if (nodes.empty()) return false;
+    who = WorldIndex{};
+    const float inv[3] = {1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z};
+    uint32_t stack[96];
+    int sp = 0;
+    stack[sp++] = root;
+    bool any = false;
+    float closest = t_max;
+    HitRecord rec;
+    while (sp) {
+      const Node& nd = nodes[stack[--sp]];
+      float tn;
+      if (!grown_box(nd, ray, inv, t_min, closest, tn)) continue;
+      if (nd.left & LEAF) {
+        const uint32_t first = nd.left & ~LEAF;
+        for (uint32_t k = first; k < first + nd.right; ++k) {
+          const WorldIndex idx = order[k];
+          if (!world.hit_object(idx, ray, t_min, closest, rec)) continue;
+          // World::hit keeps the later object of its scan on an equal t (world.rs:75-94)
+          const bool later = idx.type_index > who.type_index ||
+                             (idx.type_index == who.type_index && idx.object_index > who.object_index);
+          if (!any || rec.t < closest || later) { any = true; closest = rec.t; out = rec; who = idx; }
+        }
+      } else if (sp + 2 <= 96) {
+        float tl, tr;
+        const bool hl = grown_box(nodes[nd.left], ray, inv, t_min, closest, tl);
+        const bool hr = grown_box(nodes[nd.right], ray, inv, t_min, closest, tr);
+        if (hl && hr) {
+          const bool left_first = tl <= tr;
+          stack[sp++] = left_first ? nd.right : nd.left;
+          stack[sp++] = left_first ? nd.left : nd.right;
+        } else if (hl) stack[sp++] = nd.left;
+        else if (hr) stack[sp++] = nd.right;
+      }
+    }
+    return any;
+  }
+  bool hit(const Ray& ray, float t_min, float t_max, HitRecord& out) const override {
+    WorldIndex who;
+    return hit_indexed(ray, t_min, t_max, out, who);
+  }
+  AABB bounding_box() const override { return world.bounding_box(); }
+  void number_media(uint32_t& n) override { world.number_media(n); }
+};
+
+// ---------------------------------------------------------------------------
 // camera.rs
 // ---------------------------------------------------------------------------
 struct Camera {

@@ -24,6 +24,7 @@ struct Scene {
   std::unique_ptr<Hittable> hittable;  // World or BVH
   World* world = nullptr;              // set when hittable is a World
   BVH* bvh = nullptr;                  // set when hittable is a BVH
+  CulledBVH* culled = nullptr;         // set when hittable is the culling container (large-scene baseline, not in the reference)
   std::unique_ptr<Hittable> lights;    // may be null
   Point3 look_from, look_at;
   Vec3 v_up;
@@ -175,7 +176,7 @@ Scene* build_scene(const std::string& name, uint64_t scene_seed, const std::stri
   SceneRng rng(scene_seed);
   const LambSolid dummy(SolidTexture(Color(0.4f, 0.2f, 0.1f)));
   if (name == "spheres" || name == "spheres_bvh" || name.rfind("synthetic:", 0) == 0 ||
-      name.rfind("synthetic_bvh:", 0) == 0) {
+      name.rfind("synthetic_bvh:", 0) == 0 || name.rfind("synthetic_culled:", 0) == 0) {
     int half = 11;
     bool inclusive = false;
     bool use_bvh = (name == "spheres_bvh");
@@ -187,7 +188,11 @@ Scene* build_scene(const std::string& name, uint64_t scene_seed, const std::stri
     }
     World w = weekend_scene(rng, half, inclusive);
     weekend_camera(*s);
-    if (use_bvh) {
+    if (name.rfind("synthetic_culled:", 0) == 0) {  // the same World behind a box test that culls (see CulledBVH)
+      auto c = std::make_unique<CulledBVH>(CulledBVH::from_world(std::move(w)));
+      s->culled = c.get();
+      s->hittable = std::move(c);
+    } else if (use_bvh) {
       auto b = std::make_unique<BVH>(BVH::from_world(std::move(w), 0.0f, 1.0f));  // spheres_bvh.rs:12
       s->bvh = b.get();
       s->hittable = std::move(b);
@@ -258,7 +263,7 @@ void oracle_scene_camera(void* h, float aspect, float cam[24], float background[
 }
 uint32_t oracle_scene_object_count(void* h) {
   Scene* s = static_cast<Scene*>(h);
-  const World* w = s->world ? s->world : &s->bvh->world;
+  const World* w = s->world ? s->world : (s->culled ? &s->culled->world : &s->bvh->world);
   uint32_t n = 0;
   for (const auto& col : w->data) n += (uint32_t)col.size();
   return n;
@@ -387,8 +392,9 @@ int oracle_scene_trace(void* h, const float* rays, size_t n, uint64_t seed, uint
         sampler.begin(0, STAGE_MEDIA);
         HitRecord rec;
         WorldIndex who;
-        const bool ok = s->bvh ? s->bvh->hit_indexed(r, 0.001f, INF_F, rec, who)
-                               : s->world->hit_indexed(r, 0.001f, INF_F, rec, who);
+        const bool ok = s->culled ? s->culled->hit_indexed(r, 0.001f, INF_F, rec, who)
+                        : s->bvh  ? s->bvh->hit_indexed(r, 0.001f, INF_F, rec, who)
+                                  : s->world->hit_indexed(r, 0.001f, INF_F, rec, who);
         type_index[i] = ok ? who.type_index : 0xFFFFFFFFu;
         object_index[i] = ok ? who.object_index : 0xFFFFFFFFu;
         t_out[i] = ok ? rec.t : INF_F;
@@ -451,7 +457,9 @@ int oracle_scene_hit_records_full(void* h, const float* rays, size_t n, uint64_t
     sampler.begin(0, STAGE_MEDIA);
     HitRecord rec;
     WorldIndex who;
-    const bool ok = s->bvh ? s->bvh->hit_indexed(r, 0.001f, INF_F, rec, who) : s->world->hit_indexed(r, 0.001f, INF_F, rec, who);
+    const bool ok = s->culled ? s->culled->hit_indexed(r, 0.001f, INF_F, rec, who)
+                    : s->bvh  ? s->bvh->hit_indexed(r, 0.001f, INF_F, rec, who)
+                              : s->world->hit_indexed(r, 0.001f, INF_F, rec, who);
     float* o = out + 16 * i;
     for (int k = 0; k < 16; ++k) o[k] = 0.0f;
     o[3] = INF_F;

@@ -370,6 +370,57 @@ class ExampleScene:
         return ti, oi, t
 
 
+class SharedScene:
+    """An example scene uploaded through one context over several GPUs (mirt_context_create_multi): mirt_render then
+    shares the frame out between them inside the library -- row bands x sample ranges, one host thread per device,
+    the other devices' rows copied to the first one and added there (the counterpart of the reference's strip
+    threads, renderer.rs:55-87)."""
+
+    def __init__(self, name, devices, row_bands=0, scene_seed=1, asset_dir=None):
+        self.L = mirt()
+        self.X = examples()
+        self.ctx = C.c_void_p()
+        self.scene = C.c_void_p()
+        self.lowered = self.X.rt_lowered_open(name.encode(), scene_seed, str(asset_dir or ASSET_DIR).encode())
+        if not self.lowered:
+            raise MirtError(self.X.rt_example_last_error().decode())
+        ids = (C.c_int * len(devices))(*devices)
+        rc = self.L.mirt_context_create_multi(ids, len(devices), row_bands, C.byref(self.ctx))
+        if rc != 0:
+            raise MirtError(f"status {rc}: {self.L.mirt_last_error(None).decode()}")
+        rc = self.X.rt_lowered_upload(self.lowered, self.ctx, C.byref(self.scene))
+        if rc != 0:
+            raise MirtError(f"status {rc}: {self.L.mirt_last_error(self.ctx).decode()}")
+
+    def render(self, cam, background, width, height, spp, depth, seed=7, first_sample=0, first_row=0, n_rows=0,
+               flags=0, path_pool=0, want_sums=True):
+        """mirt_render into host buffers: (rgb24 HxWx3 u8, sums HxWx3 f32 or None, stats dict)."""
+        p = RenderParams(width, height, spp, first_sample, depth, (C.c_float * 3)(*background), seed, path_pool, flags,
+                         first_row, n_rows)
+        rgb = np.zeros((height, width, 3), np.uint8)
+        sums = np.zeros((height, width, 3), np.float32) if want_sums else None
+        st = Stats()
+        rc = self.L.mirt_render(self.ctx, self.scene, C.byref(cam), C.byref(p), rgb.ctypes.data,
+                                sums.ctypes.data if want_sums else None, C.byref(st))
+        if rc != 0:
+            raise MirtError(f"status {rc}: {self.L.mirt_last_error(self.ctx).decode()}")
+        return rgb, sums, st.as_dict()
+
+    def close(self):
+        if self.scene:
+            self.L.mirt_scene_destroy(self.ctx, self.scene)
+            self.scene = C.c_void_p()
+        if self.ctx:
+            self.L.mirt_context_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+        if self.lowered:
+            self.X.rt_lowered_close(self.lowered)
+            self.lowered = None
+
+    def __del__(self):
+        self.close()
+
+
 RECORD_DTYPE = np.dtype([("point", np.float32, 3), ("t", np.float32), ("normal", np.float32, 3),
                          ("front_face", np.uint32), ("u", np.float32), ("v", np.float32), ("type_index", np.uint32),
                          ("object_index", np.uint32), ("color", np.float32, 3), ("material_kind", np.uint32)])

@@ -44,6 +44,26 @@ def random_rays(n, lo, hi, seed, time_lo=0.0, time_hi=1.0):
     return rays
 
 
+def skimming_rays(n, half, seed):
+    """Rays that cross a sphere field of half-width `half` just above its spheres (tops at y = 0.4), sinking so
+    slowly that most travel more than `half` units, many more than 1.9 * half, before they first meet one: the
+    regime where |o - c|^2 - r^2 no longer resolves r^2 and the box growth is all that keeps a hit from being culled."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((n, 7), F)
+    angle = rng.uniform(0, 2 * np.pi, n)
+    start = rng.uniform(0.95, 1.3, n) * half                # at or beyond the rim of the field
+    rays[:, 0] = -np.cos(angle) * start + rng.uniform(-0.3, 0.3, n) * half
+    rays[:, 2] = -np.sin(angle) * start + rng.uniform(-0.3, 0.3, n) * half
+    rays[:, 1] = rng.uniform(0.45, 3.0, n)
+    reach = rng.uniform(0.8, 2.6, n) * half                  # where the ray comes down to the spheres' tops
+    scale = rng.uniform(0.2, 3.0, n)                         # directions are not unit length in the reference either
+    rays[:, 3] = np.cos(angle) * scale
+    rays[:, 5] = np.sin(angle) * scale
+    rays[:, 4] = -(rays[:, 1] - 0.4) / reach * scale
+    rays[:, 6] = rng.uniform(0, 1, n)
+    return rays
+
+
 def assert_same_hits(g, o, rays, exact_t=True):
     ti, oi, t = g.trace(rays)
     oti, ooi, ot = o.trace(rays)
@@ -330,6 +350,25 @@ def test_large_scene_library_defaults(scenes):
     ok = np.isfinite(osums).all(axis=2)
     close = np.isclose(sums, osums, rtol=1e-4, atol=1e-5).all(axis=2)
     assert np.mean(close[ok]) > 0.98                       # a libm rounding may flip a path
+
+
+def test_million_sphere_field_against_the_linear_scan():
+    """A field of 1 002 003 spheres (the synthetic scene at half = 500) on the library's defaults, ids and t bits
+    against the oracle's linear World::hit scan (world.rs:75-94: every sphere against every ray): camera rays,
+    rays inside the field, and rays that skim the field for up to 1300 units before they meet a sphere."""
+    g, o = R.ExampleScene("synthetic:500"), O.Scene("synthetic:500")
+    try:
+        assert g.primitive_count() == o.object_count() == 1002003
+        cam, _ = g.camera()
+        rays = np.concatenate([R.camera_rays(cam, 32, 18), skimming_rays(500, 500, 7),
+                               random_rays(300, [-500, 0.0, -500], [500, 2, 500], 8)])
+        ti, oi, t = assert_same_hits(g, o, rays)
+        hit = ti != 0xFFFFFFFF
+        travelled = np.linalg.norm(rays[:, 3:6], axis=1) * np.where(hit, t, 0.0)
+        assert (travelled > 500).sum() > 100 and travelled.max() > 900, (int((travelled > 500).sum()), float(travelled.max()))
+    finally:
+        g.close()
+        o.close()
 
 
 @pytest.mark.parametrize("slices", ["4", "7"])

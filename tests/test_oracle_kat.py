@@ -522,3 +522,34 @@ def test_light_sampling_keeps_a_furnace_in_balance(with_sphere):
     objects.rs:82-100, 292-309 and world.rs:100-117 match the way they are drawn."""
     got = O.kat_furnace(with_sphere, 0.5, 0.5, 200000, seed=11)
     assert abs(got - 0.25) < 0.0025, got
+
+
+def test_culling_container_equals_the_linear_scan():
+    """oracle.hpp's CulledBVH is not in the reference: it stands in for the reference's exhaustive containers where
+    those would take hours (the CPU baseline and the checker of ten-million-sphere scenes).  It must return what
+    World::hit's scan returns (world.rs:75-94), ids and t bits, also for rays that skim a field for a thousand
+    units, where the f32 sphere test reports hits far off the spheres."""
+    half = 150
+    a, c = O.Scene(f"synthetic:{half}"), O.Scene(f"synthetic_culled:{half}")
+    assert a.object_count() == c.object_count() > 90000
+    rng = np.random.default_rng(12)
+    n = 600
+    rays = np.zeros((n, 7), np.float32)
+    angle = rng.uniform(0, 2 * np.pi, n)
+    start = rng.uniform(0.95, 1.3, n) * half
+    rays[:, 0] = -np.cos(angle) * start
+    rays[:, 2] = -np.sin(angle) * start
+    rays[:, 1] = rng.uniform(0.45, 3.0, n)
+    reach = rng.uniform(0.8, 2.6, n) * half
+    scale = rng.uniform(0.2, 3.0, n)
+    rays[:, 3] = np.cos(angle) * scale
+    rays[:, 5] = np.sin(angle) * scale
+    rays[:, 4] = -(rays[:, 1] - 0.4) / reach * scale
+    rays[:, 6] = rng.uniform(0, 1, n)
+    cam, _ = a.camera()
+    rays = np.concatenate([rays, O.pixel_centre_rays(cam, 48, 27)])
+    ti, oi, t = a.trace(rays)
+    cti, coi, ct = c.trace(rays)
+    assert np.array_equal(ti, cti) and np.array_equal(oi, coi)
+    assert np.array_equal(t.view(np.uint32), ct.view(np.uint32))
+    assert (ti != 0xFFFFFFFF).sum() > 800
