@@ -951,6 +951,17 @@ __device__ __noinline__ void check_failed(WorkCounters* wc, uint32_t site, uint3
 #define MIRT_CHECK(ok, wc, site, a, b, c) true
 #endif
 
+// Number of lanes below this one whose bit is set in `mask` (a ballot): two v_mbcnt instructions.
+// (Written as popcount(mask & ((1 << lane) - 1)) the compiler forms the lane mask with a 64-bit shift by the lane
+// id, v_lshlrev_b64.  On gfx950 the 64-bit shifts read their 32-bit shift amount as a register pair: when the
+// register allocator puts the amount in the last register of the wave's allocation, every wave but the first on
+// its SIMD reads 0 for it -- tools/shift_hazard_probe.hip -- and a build whose scheduling led to exactly that
+// allocation packed all survivors of a batch into one slot.  No variable 64-bit shift is left in this file;
+// tools/check_isa.py holds every build to it.)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // Reserves one slot per lane that passes `pred` with a single atomic per wave.
 __device__ __forceinline__ uint32_t wave_reserve(bool pred, uint32_t* counter) {
   const unsigned long long mask = __ballot(pred);
@@ -960,7 +971,7 @@ __device__ __forceinline__ uint32_t wave_reserve(bool pred, uint32_t* counter) {
   uint32_t base = 0;
   if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
   base = __shfl(base, leader);
-  return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  return base + lanes_below(mask);
 }
 
 __device__ __forceinline__ int queue_of(uint32_t material_word) { return (int)(material_word >> 28); }
@@ -1251,7 +1262,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       const unsigned long long m_spent = LDS_SCENE ? 0ull : __ballot(spent);
       unsigned long long m_free = __ballot(done) | __ballot(slot == NO_SLOT);
       uint32_t n_free = (uint32_t)__popcll(m_free);
-      uint32_t rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
+      uint32_t rank = lanes_below(m_free);
       if (AHEAD && more && base < n_stored) {
         // the rays the free lanes will take, out of the lanes that hold them, and the loads for the next exchange
         r0 = from_lane(ahead[0], rank << 2);
@@ -1265,7 +1276,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       if (q == QUEUE_LAMBERTIAN && ref_tag(w.best_ref) >= TAG_RECT) q = QUEUE_LAMBERTIAN_FLAT;
       uint32_t saved_at = 0;  // 1 + entry of the save area
       if (!LDS_SCENE && spent) {
-        const uint32_t at = n_saved + (uint32_t)__popcll(m_spent & ((1ull << lane) - 1ull));
+        const uint32_t at = n_saved + lanes_below(m_spent);
         if (at < save_cap) {
           saved_at = at + 1u;
           q = QUEUE_CONTINUE;
@@ -1285,7 +1296,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       if (!LDS_SCENE) {
         m_free = __ballot(leaving) | __ballot(slot == NO_SLOT);
         n_free = (uint32_t)__popcll(m_free);
-        rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
+        rank = lanes_below(m_free);
       }
       unsigned long long mq = 0ull;  // the lanes handing in to the same queue as this one
       uint32_t cnt = 0;
@@ -1299,7 +1310,7 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
       queue_fill += cnt;
       const uint32_t bq = __shfl(got, q < 0 ? 0 : q);  // every lane takes part: the lanes that keep the fills may not be done
       if (leaving) {
-        const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+        const uint32_t pos = bq + lanes_below(mq);
         // the whole path record moves into the queue, hit included: shading reads its queue front to back
         float4* const out = region_queues + 4 * (size_t)q * cap + pos;
         if (MIRT_CHECK(pos < cap && q < N_QUEUES, A->work, 2, pos, cap, q)) {
@@ -1457,7 +1468,7 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
     if (lane < (uint32_t)N_QUEUES && cnt) got = atomicAdd(&sh.queue_n[lane], cnt);
     const uint32_t bq = __shfl(got, q < 0 ? 0 : q);
     if (live) {
-      const uint32_t pos = bq + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+      const uint32_t pos = bq + lanes_below(mq);
       float4* const out = region_queues + 4 * (size_t)q * cap + pos;
       out[0] = r0;
       out[cap] = r1;
@@ -1882,6 +1893,44 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     if (COUNT) work.cycles[MIRT_PHASE_SHADE] += clock64() - ts;
     wave_sync();
     n_surv = uniform(sh.n_next);
+#ifdef MIRT_SURVIVOR_AUDIT
+    // Diagnostic build: what shading left in the region's other buffer, looked at from outside the shading code (whose
+    // code generation this leaves untouched).  Per wave of the block: survivors counted by shading, and records among
+    // them whose bounce field is not this round's number -- a slot no lane wrote.
+    if (!tracing) {
+      ConstArgs A = pinned(args);
+      const uint32_t cap = A->rc.region_cap;
+      const float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region_of_wave(A) * cap;
+      uint32_t stale = 0;
+      for (uint32_t k = lane_id(); k < n_surv; k += 64u)
+        if ((__float_as_uint(next[2 * (size_t)cap + k].w) & 255u) != rounds) ++stale;
+      for (int off = 32; off > 0; off >>= 1) stale += __shfl_down(stale, off);
+      stale = uniform(stale);
+      if (lane_id() == 0) {
+        atomicAdd(&A->work->audit[wave_in_block()], (unsigned long long)n_surv);
+        atomicAdd(&A->work->audit[16 + wave_in_block()], (unsigned long long)stale);
+      }
+      // the first region found with such slots: which ones (a bit per slot, 64 slots per word), and what the round's
+      // queues held
+      if (stale != 0) {
+        unsigned long long first = 1ull;
+        if (lane_id() == 0) first = atomicCAS(&A->work->check[7], 0ull, 1ull);
+        first = ((unsigned long long)uniform((uint32_t)(first >> 32)) << 32) | uniform((uint32_t)first);
+        if (first == 0ull) {
+          for (uint32_t w = 0; w < 6u; ++w) {
+            const uint32_t k = w * 64u + lane_id();
+            const bool bad = k < n_surv && (__float_as_uint(next[2 * (size_t)cap + k].w) & 255u) != rounds;
+            const unsigned long long m = __ballot(bad);
+            if (lane_id() == 0) A->work->check[w] = m;
+          }
+          if (lane_id() == 0) {
+            A->work->check[6] = ((unsigned long long)n_surv << 32) | (wave_in_block() << 16) | rounds;
+            for (int q = 0; q < N_QUEUES; ++q) A->work->audit[q] |= (unsigned long long)sh.queue_n[q] << 40;
+          }
+        }
+      }
+    }
+#endif
   }
 
   WorkCounters* const work_out = pinned(args)->work;

@@ -909,13 +909,13 @@ struct Workspace {
 
 // The fixed workspace, cut up: [control page: state, counters, arguments][paths a][paths b][queues].
 Workspace carve_static_workspace(void* base) {
-  static_assert(sizeof(RenderState) <= 256 && sizeof(WorkCounters) <= 256 && sizeof(RenderArgs) <= STATIC_CONTROL_BYTES - 512,
+  static_assert(sizeof(RenderState) <= 256 && sizeof(WorkCounters) <= 512 && sizeof(RenderArgs) <= STATIC_CONTROL_BYTES - 768,
                 "the control page of the fixed workspace is too small");
   unsigned char* p = static_cast<unsigned char*>(base);
   Workspace w;
   w.state = reinterpret_cast<RenderState*>(p);
   w.work = reinterpret_cast<WorkCounters*>(p + 256);
-  w.args = reinterpret_cast<RenderArgs*>(p + 512);
+  w.args = reinterpret_cast<RenderArgs*>(p + 768);
   p += STATIC_CONTROL_BYTES;
   w.paths[0] = reinterpret_cast<float4*>(p);
   w.paths[1] = reinterpret_cast<float4*>(p + (size_t)STATIC_POOL_PATHS * 64);
@@ -1058,6 +1058,23 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   if (time_kernels) MIRT_HIP(ctx, hipEventRecord(ev[1], stream));
   MIRT_HIP(ctx, hipStreamSynchronize(stream));
   const auto t_end = std::chrono::steady_clock::now();
+#ifdef MIRT_SURVIVOR_AUDIT
+  {
+    WorkCounters w{};
+    MIRT_HIP(ctx, hipMemcpy(&w, ws.work, sizeof(w), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "mirt audit: survivors / unwritten slots per wave of a block:");
+    for (int k = 0; k < 16; ++k) std::fprintf(stderr, " %llu/%llu", w.audit[k] & 0xFFFFFFFFFFull, w.audit[16 + k]);
+    std::fprintf(stderr, "\n");
+    if (w.check[7]) {
+      std::fprintf(stderr, "mirt audit: first region with unwritten slots: %llu survivors, wave %llu of its block, round %llu; queues of that round:",
+                   w.check[6] >> 32, (w.check[6] >> 16) & 0xFFFF, w.check[6] & 0xFFFF);
+      for (int q = 0; q < N_QUEUES; ++q) std::fprintf(stderr, " %llu", w.audit[q] >> 40);
+      std::fprintf(stderr, "\n   unwritten slots, 64 per word from slot 0:");
+      for (int k = 0; k < 6; ++k) std::fprintf(stderr, " %016llx", w.check[k]);
+      std::fprintf(stderr, "\n");
+    }
+  }
+#endif
 #ifdef MIRT_CHECKED
   {  // diagnostic build: an index the kernel found out of range ends the call with what it recorded
     WorkCounters w{};

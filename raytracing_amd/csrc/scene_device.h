@@ -202,6 +202,9 @@ struct WorkCounters {
   // diagnostic build (MIRT_CHECKED) only: site of the first index found out of range (0 = none), the three values
   // recorded there, block and thread that found it, number of violations in all
   unsigned long long check[8];
+  // diagnostic build (MIRT_SURVIVOR_AUDIT) only, per wave of a block: survivors shading counted, slots among them
+  // that no lane wrote
+  unsigned long long audit[32];
 };
 
 // Hits are shaded queue by queue so that a wave runs one material's code: Lambertian surfaces of one colour,

@@ -91,7 +91,12 @@ def test_static_workspace_turns_an_overlapping_call_away():
     result = {}
 
     def long_call():
-        result["a"] = _render(L.mirt_render_accumulate_static, a, 1920, 1080, 16)
+        # (the short calls of the loop below may hold the workspace at the moment this one arrives: it is then the
+        # one turned away, and asks again)
+        for _ in range(1000):
+            result["a"] = _render(L.mirt_render_accumulate_static, a, 1920, 1080, 16)
+            if not (result["a"][0] == 1 and "in use" in result["a"][1]):
+                break
 
     # (the second caller's buffers are made beforehand: nothing in its loop waits for the device)
     cam, bg = b.camera(1.0)
