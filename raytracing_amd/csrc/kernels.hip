@@ -120,6 +120,7 @@ struct ShadeTables {
   const DTexture* textures;
   const float4* perlin_vec;     // 256 per table (xyz, -)
   const uint32_t* perlin_perm;  // 768 per table: perm_x, perm_y, perm_z
+  uint32_t perlin_lds;          // LDS address of the tables' copies (PERLIN_LDS_BYTES each: vectors, permutations as bytes), 0 = none
   const DImage* images;
   const uint8_t* image_data;
   const DLight* lights;
@@ -129,7 +130,7 @@ struct ShadeTables {
 // Both from a scene description in any address space (kernel argument or constant memory).
 #define MIRT_GLOBAL_TABLES(sc) SceneTables{(sc).nodes, (sc).prims, (sc).chains, (sc).chain_ops}
 #define MIRT_SHADE_TABLES(sc)                                                                                   \
-  ShadeTables{(sc).materials, (sc).textures, (sc).perlin_vec, (sc).perlin_perm, (sc).images, (sc).image_data, \
+  ShadeTables{(sc).materials, (sc).textures, (sc).perlin_vec, (sc).perlin_perm, 0u, (sc).images, (sc).image_data, \
               (sc).lights,    (sc).light_groups, (sc).lights_mode, (sc).n_lights, (sc).n_light_groups}
 
 // ---- wrappers (transforms.rs) --------------------------------------------------
@@ -755,12 +756,11 @@ __device__ __forceinline__ Hit hit_record(const SceneTables& tb, const MediumEnt
 }
 
 // ---- textures (texture.rs, perlin.rs) ----------------------------------------------
-__device__ __forceinline__ float perlin_noise(const ShadeTables& sc, uint32_t table, V3 p) {  // perlin.rs:26-48,75-93
+template <typename Perm, typename Vec>
+__device__ __forceinline__ float perlin_sum(Perm perm, Vec vec, V3 p) {  // perlin.rs:26-48,75-93
   const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
   const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
   const int i = (int)fx, j = (int)fy, k = (int)fz;
-  const uint32_t* perm = sc.perlin_perm + 768 * (size_t)table;
-  const float4* vec = sc.perlin_vec + 256 * (size_t)table;
   const float uu = u * u * (3.0f - 2.0f * u);
   const float vv = v * v * (3.0f - 2.0f * v);
   const float ww = w * w * (3.0f - 2.0f * w);
@@ -771,14 +771,23 @@ __device__ __forceinline__ float perlin_noise(const ShadeTables& sc, uint32_t ta
     for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
       for (int dk = 0; dk < 2; ++dk) {
-        const uint32_t h = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
-        const V3 c = xyz(vec[h]);
+        const uint32_t h = (uint32_t)perm[(i + di) & 255] ^ (uint32_t)perm[256 + ((j + dj) & 255)] ^ (uint32_t)perm[512 + ((k + dk) & 255)];
+        const V3 c = v3(vec[h].x, vec[h].y, vec[h].z);
         const V3 weight = v3(u - (float)di, v - (float)dj, w - (float)dk);
         accum += ((float)di * uu + (1.0f - (float)di) * (1.0f - uu)) *
                  ((float)dj * vv + (1.0f - (float)dj) * (1.0f - vv)) *
                  ((float)dk * ww + (1.0f - (float)dk) * (1.0f - ww)) * dot(c, weight);
       }
   return accum;
+}
+__device__ __forceinline__ float perlin_noise(const ShadeTables& sc, uint32_t table, V3 p) {
+  if (sc.perlin_lds != 0u) {  // the block's copies: the same numbers, the permutations as bytes
+    typedef const __attribute__((address_space(3))) float4* LdsVec;
+    typedef const __attribute__((address_space(3))) uint8_t* LdsPerm;
+    const uint32_t at = sc.perlin_lds + table * PERLIN_LDS_BYTES;
+    return perlin_sum((LdsPerm)(uintptr_t)(at + 256u * 16u), (LdsVec)(uintptr_t)at, p);
+  }
+  return perlin_sum(sc.perlin_perm + 768 * (size_t)table, sc.perlin_vec + 256 * (size_t)table, p);
 }
 
 __device__ __forceinline__ float perlin_turb2(const ShadeTables& sc, uint32_t table, V3 p) {  // perlin.rs:50-60, depth 2
@@ -1554,6 +1563,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
     sc.textures = reinterpret_cast<const DTexture*>(lds.textures);
     sc.lights = reinterpret_cast<const DLight*>(lds.lights);
     sc.light_groups = reinterpret_cast<const uint2*>(lds.groups);
+    if (A->lds_perlin_offset != 0u) sc.perlin_lds = uniform(lds_arg) + A->lds_perlin_offset;
   }
   const LightList ll{sc.lights, sc.light_groups, sc.lights_mode, sc.n_lights, sc.n_light_groups};
   const SceneTables gt = MIRT_GLOBAL_TABLES(A->sc);
@@ -1873,6 +1883,15 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       for (uint32_t k = threadIdx.x; k < n_texture_quads; k += threads) lds.textures[k] = textures[k];
       for (uint32_t k = threadIdx.x; k < n_light_quads; k += threads) lds.lights[k] = lights[k];
       for (uint32_t k = threadIdx.x; k < n_groups; k += threads) reinterpret_cast<uint2*>(lds.groups)[k] = groups[k];
+      if (A->lds_perlin_offset != 0u) {
+        unsigned char* const to = reinterpret_cast<unsigned char*>(smem) + A->lds_perlin_offset;
+        const float4* const vec = A->sc.perlin_vec;
+        const uint32_t* const perm = A->sc.perlin_perm;
+        for (uint32_t t = 0; t < A->sc.n_perlins; ++t) {
+          for (uint32_t k = threadIdx.x; k < 256u; k += threads) reinterpret_cast<float4*>(to + t * PERLIN_LDS_BYTES)[k] = vec[256u * t + k];
+          for (uint32_t k = threadIdx.x; k < 768u; k += threads) to[t * PERLIN_LDS_BYTES + 4096u + k] = (unsigned char)perm[768u * t + k];
+        }
+      }
     }
   }
   __syncthreads();  // the staged scene is complete: the one time the waves of a block wait for each other
@@ -2092,6 +2111,12 @@ RenderConfig plan_render(const DeviceScene& sc) {
     cfg.lds_scene = true;
     cfg.stack_depth = depth;
     cfg.lds_bytes = lds_total;
+    // (noise textures gather from their tables sixteen times a lookup: from LDS when there is room behind the stacks)
+    const size_t perlin_bytes = (size_t)sc.n_perlins * PERLIN_LDS_BYTES;
+    if (sc.n_perlins != 0 && lds_total + perlin_bytes <= LDS_BYTES_PER_CU && !std::getenv("MIRT_NO_LDS_PERLIN")) {
+      cfg.lds_perlin_offset = (uint32_t)lds_total;
+      cfg.lds_bytes = lds_total + perlin_bytes;
+    }
   } else {
     cfg.lds_scene = false;
     cfg.stack_depth = WIDE_LDS_STACK;

@@ -844,6 +844,7 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   v.chains = s.chains.as<float4>();
   v.chain_ops = s.chain_ops.as<float4>();
   v.n_media = d.n_media;
+  v.n_perlins = d.n_perlins;
   std::vector<DMedium> media(d.n_media);
   for (uint32_t i = 0; i < d.n_media; ++i) {
     const mirt_medium& m = d.media[i];
@@ -1047,6 +1048,7 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   args.saves = ws.saves;
   args.node_min = cfg.node_min;
   args.prims_per_turn = cfg.prims_per_turn;
+  args.lds_perlin_offset = cfg.lds_perlin_offset;
   args.rays = job.rays;
   args.hit_type = job.hit_type;
   args.hit_object = job.hit_object;

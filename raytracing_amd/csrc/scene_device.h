@@ -147,6 +147,7 @@ struct DeviceScene {
   uint32_t n_slices;
   float slice_time0, slice_scale;
   uint32_t wide;  // nodes are four-child WideNodes (the scene is walked from global memory)
+  uint32_t n_perlins;  // noise tables (256 vectors and 3 x 256 permutation entries each)
   uint32_t keep_out;  // never staged in LDS, whatever its size (MIRT_NO_LDS at upload: a small scene through the large scenes' code)
 
   const float4* prims;  // primitive records, layout above
@@ -287,6 +288,7 @@ hipError_t static_workspace_address(int device, void** out);
 // How the render kernel is launched for a scene: one block per CU, one region per wave, with nodes, primitive
 // records, wrapper chains, materials, textures and the light list staged in LDS when they fit beside the block's
 // traversal stacks, else read from global memory.
+constexpr uint32_t PERLIN_LDS_BYTES = 256 * 16 + 768;  // one noise table in LDS
 struct RenderConfig {
   bool lds_scene;
   int block;  // threads per block: a multiple of 64, at most RENDER_THREADS
@@ -297,6 +299,9 @@ struct RenderConfig {
   uint32_t refill_min;  // a wave hands in finished rays and fetches new ones once this many lanes have none
   uint32_t node_min;    // a wave keeps stepping down the tree while this many of its lanes hold an inner node
   uint32_t prims_per_turn;  // primitive tests a lane makes, one after the other, between two runs of tree steps
+  // Scenes staged in LDS with room to spare: the noise tables go behind the stacks, vectors as they are, the
+  // permutations as bytes (4864 bytes a table); byte offset of the first table in the block's LDS, 0 = not staged
+  uint32_t lds_perlin_offset;
 };
 RenderConfig plan_render(const DeviceScene& sc);
 // Everything the render kernel is told, read by it from device memory.
@@ -310,6 +315,7 @@ struct RenderArgs {
   WorkCounters* work;
   float* rgb_sum;
   uint32_t refill_min, node_min, prims_per_turn;
+  uint32_t lds_perlin_offset;  // RenderConfig::lds_perlin_offset
   uint32_t waves_per_block;  // block size of the launch / 64; wave w of block b owns region b * waves_per_block + w
   // Scenes walked from global memory: a ray takes at most this many steps (tree steps + primitive tests) per
   // round; then its walk is put aside in `saves` (save_cap entries of SAVE_QUADS quads per region and round

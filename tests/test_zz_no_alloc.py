@@ -86,6 +86,7 @@ def test_static_workspace_call_leaves_device_memory_alone():
 def test_static_workspace_turns_an_overlapping_call_away():
     """Two calls at once on one GPU would share the workspace: the second is rejected, not raced."""
     import threading
+    import time
     L = R.mirt()
     a, b = R.ExampleScene("final_scene"), R.ExampleScene("cornel_box")     # two contexts, one GPU
     result = {}
@@ -97,6 +98,7 @@ def test_static_workspace_turns_an_overlapping_call_away():
             result["a"] = _render(L.mirt_render_accumulate_static, a, 1920, 1080, 16)
             if not (result["a"][0] == 1 and "in use" in result["a"][1]):
                 break
+            time.sleep(0.001)
 
     # (the second caller's buffers are made beforehand: nothing in its loop waits for the device)
     cam, bg = b.camera(1.0)
@@ -114,6 +116,7 @@ def test_static_workspace_turns_an_overlapping_call_away():
         else:
             assert rc == 0, L.mirt_last_error(ctx).decode()
             accepted += 1
+            time.sleep(0.005)      # (a gap for the long call to get in)
     t.join()
     rc, msg, img, _ = result["a"]
     assert rc == 0, msg
