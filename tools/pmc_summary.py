@@ -15,4 +15,4 @@ for d in sys.argv[1:]:
 for k, v in agg.items():
     print(k, "dispatches", len(calls[k]))
     for c in sorted(v):
-        print(f"   {c:28s} {v[c]:.4g}")
+        print(f"   {c:28s} {v[c]:.0f}")
