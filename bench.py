@@ -90,7 +90,7 @@ def measured_traffic(scene, segments_per_launch):
             m = counter_run(f)
             if m.get("scene", "final_scene") == scene:
                 return m["bytes_per_segment"] * segments_per_launch, {
-                    "file": "profiles/" + name, "bytes_per_segment": m["bytes_per_segment"],
+                    "file": "profiles/" + name, "bytes_per_segment": m["bytes_per_segment"], "sq": m.get("sq"),
                     "kernel_source_hash": m.get("kernel_source_hash"), "commit": m.get("commit"), "stale": m["_stale"]}
     return None, None
 
@@ -235,6 +235,13 @@ def report(a, R, scene, world, rank0_count, first, total_spp, depth, aspect, ela
                         if traffic is not None else "nothing: no counter run of this scene on file",
                         "byte_model_bytes_per_segment": bytes_per_segment,
                         "gather_kernel": measured_ceiling("gather64"), **common}
+            # what the same counter run's SQ passes say of the vector ALUs: the walk issues its tree steps and
+            # primitive tests with partly filled waves, and that, not HBM, is the nearest roof of this launch
+            sq = (traffic_source or {}).get("sq")
+            if sq:
+                insts = sq["valu_instructions_per_segment"] * my_segments / launches
+                slots = 1024 * 2.072e9 * (ker_s / launches) / 2.5
+                roofline["issue"] = {"frac": insts / slots, "cycles_per_wave64_instruction": 2.5, "shader_clock_ghz": 2.072, **sq}
         # both models side by side, whichever roof binds (informational)
         models = {"bytes_per_segment": bytes_per_segment, "algorithmic_gb_per_s": gbs,
                   "flops_per_segment": flops_per_segment, "algorithmic_tflop_per_s": tf,
