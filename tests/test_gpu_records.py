@@ -112,14 +112,20 @@ def test_spheres_records(scenes):
     assert inside.sum() > 100                                         # rays that start inside spheres
 
 
+@pytest.mark.parametrize("pairs", [False, True])
 @pytest.mark.parametrize("name,medium_type,texel_types,box,seed", [("cornel_box", None, (), ([1, 1, 1], [554, 554, 554]), 24),
                                                                    ("final_scene", 5, (6,), ([-200, 20, -200], [600, 540, 600]), 25)])
-def test_records_of_small_scenes_walked_like_large_ones(name, medium_type, texel_types, box, seed, monkeypatch):
+def test_records_of_small_scenes_walked_like_large_ones(name, medium_type, texel_types, box, seed, pairs, monkeypatch):
     """MIRT_NO_LDS keeps a scene out of LDS: its tree is folded into four-child nodes with quantised boxes and walked
     from global memory, its records, wrapper chains, materials and lights are read from there -- the code a scene of
     more than 4096 primitives runs, here with every kind of primitive, wrapper, medium and texture the examples
-    have.  Same records as the oracle's, to the same bars, and a same-seed frame that matches per pixel."""
+    have.  Same records as the oracle's, to the same bars, and a same-seed frame that matches per pixel.
+    `pairs`: two primitives of a leaf per turn, as scenes from a quarter of a million primitives up are walked --
+    here on the host builder's leaves of up to four, with rects, boxes, moving spheres and wrapped primitives going
+    through the turn that fetches both records at once."""
     monkeypatch.setenv("MIRT_NO_LDS", "1")
+    if pairs:
+        monkeypatch.setenv("MIRT_PRIMS_PER_TURN", "2")
     g, o = R.ExampleScene(name), O.Scene(name)
     try:
         cam, _ = g.camera()
