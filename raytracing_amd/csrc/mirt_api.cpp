@@ -939,9 +939,11 @@ int run_job(mirt_context* ctx, const mirt_scene* scene, Job& job, hipStream_t st
   const uint32_t granule = regions * 64u;
   // (left to the library: a sixteenth of the job's paths, between 8 Mi and 32 Mi -- 5 to 21 GB of records; on a 1080p
   // frame 32 Mi is worth 3.5 % over 8 Mi at 1024 spp, 16 Mi 1.4 % at 128 spp; 4 Mi would cost 15 %, 2 Mi half)
+  // (scenes walked from global memory: an eighth -- their rounds are longer and their regions' tails cost more; on the
+  // 10 M-sphere frame at 64 spp 16 Mi is worth 4 % over 8 Mi, 32 Mi no more)
   uint64_t want = job.want_pool ? job.want_pool
                   : job.fixed_workspace ? STATIC_POOL_PATHS
-                                        : std::min<uint64_t>(std::max<uint64_t>(total / 16, 1u << 23), 1u << 25);
+                                        : std::min<uint64_t>(std::max<uint64_t>(total / (cfg.lds_scene ? 16 : 8), 1u << 23), 1u << 25);
   want = std::min<uint64_t>(want, total);
   want = std::min<uint64_t>(std::max<uint64_t>(want, granule), 1u << 27);
 
