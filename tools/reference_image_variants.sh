@@ -3,7 +3,7 @@
 #   here:        bash tools/reference_image_variants.sh build ln|metal_absorbs|medium_normal_flipped
 #   on the box:  bash tools/reference_image_variants.sh render NAME   -> gpurun_out/final_scene_500_NAME.png
 # Region means of such a frame against tests/golden/reference_final_scene_500x500.npz: tests/test_reference_image.py's
-# discs (the figures DESIGN quotes were taken at 2048 spp, depth 50).
+# discs (the figures quoted for these variants were taken at 2048 spp, depth 50).
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=$1; name=$2
