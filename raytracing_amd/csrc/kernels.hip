@@ -431,18 +431,28 @@ __device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float 
   const uint32_t nx = up_x ? lox : hix, ny = up_y ? loy : hiy, nz = up_z ? loz : hiz;
   const uint32_t fx = up_x ? hix : lox, fy = up_y ? hiy : loy, fz = up_z ? hiz : loz;
   const float ax = fabsf(w.inv.x), ay = fabsf(w.inv.y), az = fabsf(w.inv.z);
-  // plane = fma(byte, 2^e, origin): the operation the builder checked its rounding with
+  // The builder checked every plane as P = fma(byte, 2^e, corner), rounded once, and the planes wanted here are
+  // P - o.  They are decoded relative to the ray instead, fma(byte, 2^e, corner - o): three subtractions a node in
+  // place of six a child.  byte * 2^e is exact, so with u = 2^-24 the two ways differ by at most
+  // u |corner - o| + u |P| (the rounding of corner - o, and the builder's rounding of P, which this way does not
+  // repeat) besides the u |P - o| either has; |P| <= |corner| + 255 * 2^e.  That much, taken over the axes and with
+  // 5 % to spare for the second-order terms and for what it moves the padding's own length by, is added to every
+  // child's padding (`slack`): the planes then lie at least as far out as the ones the builder checked.
+  const V3 rel = xyz(q0) - w.r.o;
+  const float slack = BOX_DECODE_SLACK * __builtin_fmaf(255.0f, fmaxf(fmaxf(sx, sy), sz),
+                                                       fmaxf(fmaxf(fabsf(rel.x), fabsf(rel.y)), fabsf(rel.z)) +
+                                                           fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fabsf(q0.z)));
   auto child = [&](int k, float& t_near) {
-    const V3 near = v3(__builtin_fmaf(byte_of(nx, k), sx, q0.x), __builtin_fmaf(byte_of(ny, k), sy, q0.y),
-                       __builtin_fmaf(byte_of(nz, k), sz, q0.z)) - w.r.o;
-    const V3 far = v3(__builtin_fmaf(byte_of(fx, k), sx, q0.x), __builtin_fmaf(byte_of(fy, k), sy, q0.y),
-                      __builtin_fmaf(byte_of(fz, k), sz, q0.z)) - w.r.o;
+    const V3 near = v3(__builtin_fmaf(byte_of(nx, k), sx, rel.x), __builtin_fmaf(byte_of(ny, k), sy, rel.y),
+                       __builtin_fmaf(byte_of(nz, k), sz, rel.z));
+    const V3 far = v3(__builtin_fmaf(byte_of(fx, k), sx, rel.x), __builtin_fmaf(byte_of(fy, k), sy, rel.y),
+                      __builtin_fmaf(byte_of(fz, k), sz, rel.z));
     const float mx = fmaxf(fabsf(near.x), fabsf(far.x)), my = fmaxf(fabsf(near.y), fabsf(far.y)),
                 mz = fmaxf(fabsf(near.z), fabsf(far.z));
     // (v_sqrt_f32: one unit in the last place, part of the constant's margin)
     // (the sum of the three instead of the root, five issue slots fewer a child: 8 % more tree steps and a third more
     // primitive tests at 10 M spheres, 10 % slower)
-    const float pad = BOX_GROW_ANY * __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx)));
+    const float pad = __builtin_fmaf(BOX_GROW_ANY, __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx))), slack);
     // (near - pad) / d and (far + pad) / d along the ray, the padding folded into the fused multiply-adds; a NaN
     // (0 * inf on a plane the ray runs in) drops out of fminf / fmaxf: the axis then does not constrain
     const float ex = pad * ax, ey = pad * ay, ez = pad * az;
