@@ -1070,7 +1070,12 @@ struct WaveShared {
   uint32_t queue_n[N_QUEUES];           // entries in the region's material queues
   uint32_t n_next;                      // survivors written to the other buffer so far
   uint32_t late_n[N_QUEUES];            // entries appended to each queue for the second shading pass
-  uint32_t pad[12];
+  // Survivors are kept in two streams, split by where they head (up or down): one fills the region's buffer from slot
+  // 0 upwards (n_next counts it), the other from the last slot downwards (n_high); the next walk reads the one, then
+  // the other, so its waves hold rays of a kind.  n_low: how many of the stored rays the walk is about to read sit
+  // at the low end (the rest at the high end); split: whether shading splits at all.
+  uint32_t n_high, n_low, split;
+  uint32_t pad[9];
 };
 static_assert(sizeof(WaveShared) == 128, "one LDS row half per wave");
 struct RenderShared {
@@ -1308,8 +1313,12 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
   constexpr bool AHEAD = LDS_SCENE;
   float4 ahead[3];
   for (int k = 0; k < 3; ++k) ahead[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  // stored ray number e of the round sits in slot e (the stream at the low end) or in the high end's stream
+  const uint32_t n_low = uniform(sh.n_low), high_shift = n_stored > n_low ? cap - n_stored : 0u;
+  auto place_of = [&](uint32_t e) { return e < n_low ? e : e + high_shift; };
   auto read_ahead = [&](uint32_t first) {
-    const uint32_t e = min(first + lane, max(n_stored, 1u) - 1u);
+    uint32_t e = min(first + lane, max(n_stored, 1u) - 1u);
+    e = place_of(e);
     if (!MIRT_CHECK(e < cap, A->work, 1, e, cap, n_stored)) return;
     ahead[0] = cur[e]; ahead[1] = cur[(size_t)cap + e]; ahead[2] = cur[2 * (size_t)cap + e];
   };
@@ -1408,14 +1417,14 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         if (slot == NO_SLOT && entry < total) {
           slot = entry;
           if (entry >= n_stored) camera.start(entry - n_stored, r0, r1, r2);
-          else if (!AHEAD && MIRT_CHECK(slot < cap, A->work, 3, slot, cap, n_stored)) { r0 = cur[slot]; r1 = cur[(size_t)cap + slot]; r2 = cur[2 * (size_t)cap + slot]; }
+          else if (!AHEAD && MIRT_CHECK(place_of(slot) < cap, A->work, 3, slot, cap, n_stored)) { const uint32_t at = place_of(slot); r0 = cur[at]; r1 = cur[(size_t)cap + at]; r2 = cur[2 * (size_t)cap + at]; }
           state = r2;
           pixel_bits = r1.w;
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
           walk_begin(w, r, root, time_slice_base(r.time, n_slices, slice_time0, slice_scale, n_nodes));
           if (!LDS_SCENE && step_budget != 0u && entry < n_stored) {
-            const uint32_t saved_in = __float_as_uint(cur[3 * (size_t)cap + slot].x);
+            const uint32_t saved_in = __float_as_uint(cur[3 * (size_t)cap + place_of(slot)].x);
             if (saved_in != 0u) {  // a walk put aside in the last round: on from where it stopped
               const uint4* const sv = saves_in + (size_t)SAVE_QUADS * (saved_in - 1u);
               const uint4 a = sv[0], b = sv[1];
@@ -1600,6 +1609,7 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
   const uint32_t cap = A->rc.region_cap;
   const uint32_t estimator = A->rc.estimator;
   const bool budgeted = !LDS_SCENE && A->step_budget != 0u;
+  const bool split = uniform(sh.split) != 0u;
   float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region * cap;
   float4* const region_queues = A->queues + 4 * (size_t)region * N_QUEUES * cap;
   float* const rgb_sum = A->rgb_sum;
@@ -1745,7 +1755,17 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         }
       }
       // survivors are packed into the first slots of the region's other buffer
-      const size_t to = wave_reserve(alive, &sh.n_next);
+      // (two streams: rays that head down are kept apart from rays that head up -- from the floor they meet
+      // different things, and the next walk's waves then hold rays of a kind: primitive tests 5 % cheaper, +1 % a
+      // frame on final_scene; which stream a ray is in changes nothing about the ray)
+      size_t to;
+      if (split) {
+        const bool high = alive && nr.d.y < 0.0f;
+        const uint32_t up = wave_reserve(alive && !high, &sh.n_next), down = wave_reserve(high, &sh.n_high);
+        to = high ? (size_t)cap - 1u - down : (size_t)up;
+      } else {
+        to = wave_reserve(alive, &sh.n_next);
+      }
       if (alive && MIRT_CHECK(to < cap, A->work, 8, to, cap, q)) {
         next[to] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
         next[cap + to] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
@@ -1928,7 +1948,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
   long long k_begin = 0, ts = 0;
   if (COUNT) k_begin = clock64();
   uint32_t segments = 0, rounds = 0;
-  uint32_t n_surv = 0;      // the region carries survivors in its slots [0, n_surv)
+  uint32_t n_surv = 0;      // survivors the region carries: n_low of them in its slots [0, n_low), the rest at the high end
+  uint32_t n_low = 0;
   bool exhausted = false;   // the shared counter has handed out the render's last path (lane 0 only)
   for (;;) {
     if (lane_id() == 0) {
@@ -1957,7 +1978,10 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       }
       sh.n_fresh = fresh;
       for (int q = 0; q < N_QUEUES; ++q) { sh.queue_n[q] = 0; sh.late_n[q] = 0; }
+      sh.n_low = tracing ? n_surv + fresh : n_low;
+      sh.split = !tracing && !(LDS_SCENE && small_scene) && A->split_survivors != 0u ? 1u : 0u;
       sh.n_next = 0;
+      sh.n_high = 0;
     }
     wave_sync();
     const uint32_t n_fresh = uniform(sh.n_fresh);
@@ -1984,7 +2008,8 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
     else shade_queues<COUNT, LDS_SCENE>(args, lds_address, odd);
     if (COUNT) work.cycles[MIRT_PHASE_SHADE] += clock64() - ts;
     wave_sync();
-    n_surv = uniform(sh.n_next);
+    n_low = uniform(sh.n_next);
+    n_surv = n_low + uniform(sh.n_high);
 #ifdef MIRT_SURVIVOR_AUDIT
     // Diagnostic build: what shading left in the region's other buffer, looked at from outside the shading code (whose
     // code generation this leaves untouched).  Per wave of the block: survivors counted by shading, and records among
@@ -1994,8 +2019,9 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
       const uint32_t cap = A->rc.region_cap;
       const float4* const next = (odd ? A->paths_a : A->paths_b) + 4 * (size_t)region_of_wave(A) * cap;
       uint32_t stale = 0;
+      const uint32_t shift = n_surv > n_low ? cap - n_surv : 0u;  // (the stream at the high end)
       for (uint32_t k = lane_id(); k < n_surv; k += 64u)
-        if ((__float_as_uint(next[2 * (size_t)cap + k].w) & 255u) != rounds) ++stale;
+        if ((__float_as_uint(next[2 * (size_t)cap + (k < n_low ? k : k + shift)].w) & 255u) != rounds) ++stale;
       for (int off = 32; off > 0; off >>= 1) stale += __shfl_down(stale, off);
       stale = uniform(stale);
       if (lane_id() == 0) {
@@ -2011,7 +2037,7 @@ __global__ __launch_bounds__(RENDER_THREADS) void k_render(const RenderArgs* __r
         if (first == 0ull) {
           for (uint32_t w = 0; w < 6u; ++w) {
             const uint32_t k = w * 64u + lane_id();
-            const bool bad = k < n_surv && (__float_as_uint(next[2 * (size_t)cap + k].w) & 255u) != rounds;
+            const bool bad = k < n_surv && (__float_as_uint(next[2 * (size_t)cap + (k < n_low ? k : k + shift)].w) & 255u) != rounds;
             const unsigned long long m = __ballot(bad);
             if (lane_id() == 0) A->work->check[w] = m;
           }

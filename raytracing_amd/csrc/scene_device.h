@@ -319,6 +319,7 @@ struct RenderArgs {
   float* rgb_sum;
   uint32_t refill_min, node_min, prims_per_turn;
   uint32_t lds_perlin_offset;  // RenderConfig::lds_perlin_offset
+  uint32_t split_survivors;    // shading keeps the survivors that head down apart from those that head up (WaveShared)
   uint32_t waves_per_block;  // block size of the launch / 64; wave w of block b owns region b * waves_per_block + w
   // Scenes walked from global memory: a ray takes at most this many steps (tree steps + primitive tests) per
   // round; then its walk is put aside in `saves` (save_cap entries of SAVE_QUADS quads per region and round
