@@ -430,36 +430,38 @@ __device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float 
                  hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
   const uint32_t nx = up_x ? lox : hix, ny = up_y ? loy : hiy, nz = up_z ? loz : hiz;
   const uint32_t fx = up_x ? hix : lox, fy = up_y ? hiy : loy, fz = up_z ? hiz : loz;
-  const float ax = fabsf(w.inv.x), ay = fabsf(w.inv.y), az = fabsf(w.inv.z);
-  // The builder checked every plane as P = fma(byte, 2^e, corner), rounded once, and the planes wanted here are
-  // P - o.  They are decoded relative to the ray instead, fma(byte, 2^e, corner - o): three subtractions a node in
-  // place of six a child.  byte * 2^e is exact, so with u = 2^-24 the two ways differ by at most
-  // u |corner - o| + u |P| (the rounding of corner - o, and the builder's rounding of P, which this way does not
-  // repeat) besides the u |P - o| either has; |P| <= |corner| + 255 * 2^e.  That much, taken over the axes and with
-  // 5 % to spare for the second-order terms and for what it moves the padding's own length by, is added to every
-  // child's padding (`slack`): the planes then lie at least as far out as the ones the builder checked.
+  // The builder checked every plane as P = fma(byte, 2^e, corner), rounded once; the test wants (P - o) / d -+ pad / |d|.
+  // It is taken per plane in one fused multiply-add, byte * (2^e / d) + ((corner - o) / d -+ pad / |d|): the second
+  // term once per node and axis, one padding for the node's four children.
+  //  * The padding is taken with F over the node's whole grid, corner - o to corner - o + 255 * 2^e per axis, which
+  //    holds every child's planes (rounding is monotonic): at least each child's own F.
+  //  * Rounding, with u = 2^-24 and in units of length (times |1/d|): 2^e / d is exact; rel = corner - o rounds by
+  //    u |rel|; the node's term by u (|rel| + pad); the sum by u |P - o|; and the builder's own rounding of P, u |P| <=
+  //    u (|corner| + 255 * 2^e), is not repeated this way.  A plane tested here lies within 2 u |rel| + u |P| + u pad of
+  //    the one the builder checked, besides the u |P - o| any way of testing it has.  3 u of |rel| + |corner| +
+  //    255 * 2^e, taken over the axes and with 5 % to spare for u pad and what it moves the padding's own length by,
+  //    is added to the padding (`slack`): the planes then lie at least as far out as the ones the builder checked.
+  //  * A ray that runs in a plane's direction (d = 0 on an axis) has 1/d infinite: every product and sum on that axis
+  //    is then infinite with the sign of "does not constrain" or a NaN, which fminf / fmaxf drop -- no box is missed.
   const V3 rel = xyz(q0) - w.r.o;
+  const V3 end = v3(__builtin_fmaf(255.0f, sx, rel.x), __builtin_fmaf(255.0f, sy, rel.y), __builtin_fmaf(255.0f, sz, rel.z));
+  const float mx = fmaxf(fabsf(rel.x), fabsf(end.x)), my = fmaxf(fabsf(rel.y), fabsf(end.y)),
+              mz = fmaxf(fabsf(rel.z), fabsf(end.z));
   const float slack = BOX_DECODE_SLACK * __builtin_fmaf(255.0f, fmaxf(fmaxf(sx, sy), sz),
                                                        fmaxf(fmaxf(fabsf(rel.x), fabsf(rel.y)), fabsf(rel.z)) +
                                                            fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fabsf(q0.z)));
+  // (v_sqrt_f32: one unit in the last place, part of the constant's margin.  The sum of the three instead of the
+  // root was 8 % more tree steps and a third more primitive tests at 10 M spheres.)
+  const float pad = __builtin_fmaf(BOX_GROW_ANY, __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx))), slack);
+  const float ex = pad * fabsf(w.inv.x), ey = pad * fabsf(w.inv.y), ez = pad * fabsf(w.inv.z);
+  const V3 step = v3(sx * w.inv.x, sy * w.inv.y, sz * w.inv.z);
+  const V3 from = v3(__builtin_fmaf(rel.x, w.inv.x, -ex), __builtin_fmaf(rel.y, w.inv.y, -ey), __builtin_fmaf(rel.z, w.inv.z, -ez));
+  const V3 till = v3(__builtin_fmaf(rel.x, w.inv.x, ex), __builtin_fmaf(rel.y, w.inv.y, ey), __builtin_fmaf(rel.z, w.inv.z, ez));
   auto child = [&](int k, float& t_near) {
-    const V3 near = v3(__builtin_fmaf(byte_of(nx, k), sx, rel.x), __builtin_fmaf(byte_of(ny, k), sy, rel.y),
-                       __builtin_fmaf(byte_of(nz, k), sz, rel.z));
-    const V3 far = v3(__builtin_fmaf(byte_of(fx, k), sx, rel.x), __builtin_fmaf(byte_of(fy, k), sy, rel.y),
-                      __builtin_fmaf(byte_of(fz, k), sz, rel.z));
-    const float mx = fmaxf(fabsf(near.x), fabsf(far.x)), my = fmaxf(fabsf(near.y), fabsf(far.y)),
-                mz = fmaxf(fabsf(near.z), fabsf(far.z));
-    // (v_sqrt_f32: one unit in the last place, part of the constant's margin)
-    // (the sum of the three instead of the root, five issue slots fewer a child: 8 % more tree steps and a third more
-    // primitive tests at 10 M spheres, 10 % slower)
-    const float pad = __builtin_fmaf(BOX_GROW_ANY, __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx))), slack);
-    // (near - pad) / d and (far + pad) / d along the ray, the padding folded into the fused multiply-adds; a NaN
-    // (0 * inf on a plane the ray runs in) drops out of fminf / fmaxf: the axis then does not constrain
-    const float ex = pad * ax, ey = pad * ay, ez = pad * az;
-    const float tn = fmaxf(fmaxf(__builtin_fmaf(near.x, w.inv.x, -ex), __builtin_fmaf(near.y, w.inv.y, -ey)),
-                           fmaxf(__builtin_fmaf(near.z, w.inv.z, -ez), t_min));
-    const float tf = fminf(fminf(__builtin_fmaf(far.x, w.inv.x, ex), __builtin_fmaf(far.y, w.inv.y, ey)),
-                           fminf(__builtin_fmaf(far.z, w.inv.z, ez), w.best_t));
+    const float tn = fmaxf(fmaxf(__builtin_fmaf(byte_of(nx, k), step.x, from.x), __builtin_fmaf(byte_of(ny, k), step.y, from.y)),
+                           fmaxf(__builtin_fmaf(byte_of(nz, k), step.z, from.z), t_min));
+    const float tf = fminf(fminf(__builtin_fmaf(byte_of(fx, k), step.x, till.x), __builtin_fmaf(byte_of(fy, k), step.y, till.y)),
+                           fminf(__builtin_fmaf(byte_of(fz, k), step.z, till.z), w.best_t));
     t_near = tn;
     return tn <= tf;
   };

@@ -83,9 +83,10 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 constexpr float BOX_GROW_SPHERE = 3.814697265625e-06f;  // 2^-18
 constexpr float BOX_GROW_LINEAR = 3.814697265625e-06f;  // 2^-18
 constexpr float BOX_GROW_ANY = 1.06e-3f;
-// Four-child nodes are decoded relative to the ray origin (wide_step): what that adds to the rounding of a plane, per
-// unit of |corner - origin| + |corner| + 255 * grid spacing: 2 u = 2^-23 and 5 % (derivation at wide_step).
-constexpr float BOX_DECODE_SLACK = 1.252e-7f;
+// Four-child nodes are tested relative to the ray origin, a plane in one fused multiply-add (wide_step): what that
+// adds to the rounding of a plane, per unit of |corner - origin| + |corner| + 255 * grid spacing: 3 u = 3 * 2^-24 and
+// 5 % (derivation at wide_step).
+constexpr float BOX_DECODE_SLACK = 1.878e-7f;
 
 // Primitive records: 4 x float4 = one 64-byte line per primitive, in the order the tree lists them
 // (so a leaf's primitives are neighbours); boundary-only primitives follow at the end.
