@@ -2,7 +2,7 @@
 """Turns the raw outputs of tools/gpu_r3_profile.sh TAG (gpurun_out/TAG) into what bench.py reads and what is kept:
 profiles/valu_issue.json, profiles/hbm_traffic.json, profiles/hbm_traffic_synthetic_bvh_1581.json -- each stamped
 with the hash of the kernel sources and the commit they were measured on -- and copies of the run's summaries as
-profiles/TAG_*.   usage: make_counter_stamps.py TAG   (run in the tree the GPU run was sent from, before any
+profiles/TAG_*.   usage: make_counter_stamps.py TAG [lines]   (run in the tree the GPU run was sent from, before any
 further change to raytracing_amd/csrc/kernels.hip or scene_device.h)"""
 import csv
 import io
@@ -20,6 +20,12 @@ from bench import kernel_source_hash  # noqa: E402
 tag = sys.argv[1]
 O = ROOT / "gpurun_out" / tag
 P = ROOT / "profiles"
+if len(sys.argv) > 2 and sys.argv[2] == "lines":  # after tools/gpu_r3_lines.sh: only the bench lines and kernel stats are new
+    for f in sorted(O.iterdir()):
+        if "bench" in f.name and f.suffix == ".json" or f.name.endswith("kernel_stats.csv"):
+            shutil.copy(f, P / f"{tag}_{f.name}")
+            print("profiles/" + f"{tag}_{f.name}")
+    sys.exit(0)
 commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 dirty = subprocess.run(["git", "status", "--porcelain", "raytracing_amd/csrc"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 stamp = {"kernel_source_hash": kernel_source_hash(), "commit": commit + ("+uncommitted changes to raytracing_amd/csrc" if dirty else "")}
