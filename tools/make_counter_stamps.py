@@ -23,8 +23,8 @@ P = ROOT / "profiles"
 if len(sys.argv) > 2 and sys.argv[2] == "lines":  # after tools/gpu_r3_lines.sh: only the bench lines and kernel stats are new
     for f in sorted(O.iterdir()):
         if "bench" in f.name and f.suffix == ".json" or f.name.endswith("kernel_stats.csv"):
-            shutil.copy(f, P / f"{tag}_{f.name}")
-            print("profiles/" + f"{tag}_{f.name}")
+            shutil.copy(f, P / f"{tag}_stamped_{f.name}")
+            print("profiles/" + f"{tag}_stamped_{f.name}")
     sys.exit(0)
 commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 dirty = subprocess.run(["git", "status", "--porcelain", "raytracing_amd/csrc"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
