@@ -293,7 +293,6 @@ std::vector<QuantNode> quantize_wide(const WideBvh& wide) {
     const WideNode& w = wide.nodes[i];
     QuantNode& q = out[i];
     std::memset(&q, 0, sizeof(q));
-    q.exps = 0;
     for (int c = 0; c < 4; ++c) q.child[c] = w.child[c];
     for (int a = 0; a < 3; ++a) {
       float mn = std::numeric_limits<float>::infinity(), mx = -std::numeric_limits<float>::infinity();
@@ -301,19 +300,18 @@ std::vector<QuantNode> quantize_wide(const WideBvh& wide) {
         if (w.child[c] != 0xFFFFFFFFu) { mn = std::min(mn, w.lo[a][c]); mx = std::max(mx, w.hi[a][c]); }
       if (!(mn <= mx)) { mn = 0.0f; mx = 0.0f; }  // (no children: cannot happen for a built tree)
       q.origin[a] = mn;
-      // the smallest power-of-two spacing with 255 steps reaching the far side; one more when rounding gets in the way
-      int e = 0;
-      (void)std::frexp(std::max((mx - mn) / 255.0f, std::numeric_limits<float>::min()), &e);  // 2^(e-1) <= x < 2^e
-      bool ok = true;
-      for (;; ++e) {
-        if (e < -125) e = -125;
-        const float step = std::ldexp(1.0f, e);
+      // the smallest spacing with which 255 steps reach the far side: a 255th of the extent, and then the next
+      // floats up until every plane, decoded exactly as the device does, lies on the outside of its child's box
+      // (a few tries; should rounding keep getting in the way, twice the spacing always fits)
+      float step = std::max((mx - mn) / 255.0f, std::numeric_limits<float>::min());
+      bool ok = false;
+      for (int tries = 0; !ok && std::isfinite(step); ++tries) {
         ok = true;
         for (int c = 0; c < 4 && ok; ++c) {
           if (w.child[c] == 0xFFFFFFFFu) { q.lo[a][c] = 255; q.hi[a][c] = 0; continue; }
           float lo = std::floor((w.lo[a][c] - mn) / step);
           lo = std::min(std::max(lo, 0.0f), 255.0f);
-          while (lo > 0.0f && std::fmaf(lo, step, mn) > w.lo[a][c]) lo -= 1.0f;  // (decoded exactly as the device does)
+          while (lo > 0.0f && std::fmaf(lo, step, mn) > w.lo[a][c]) lo -= 1.0f;
           float hi = std::ceil((w.hi[a][c] - mn) / step);
           hi = std::max(hi, 0.0f);
           while (hi <= 255.0f && std::fmaf(hi, step, mn) < w.hi[a][c]) hi += 1.0f;
@@ -321,12 +319,14 @@ std::vector<QuantNode> quantize_wide(const WideBvh& wide) {
           q.lo[a][c] = (uint8_t)lo;
           q.hi[a][c] = (uint8_t)hi;
         }
-        if (ok || e >= 127) break;
+        if (!ok) step = tries < 16 ? std::nextafter(step, std::numeric_limits<float>::infinity()) : step * 2.0f;
       }
-      if (!ok)  // (bounds near the largest f32: no spacing fits; the whole grid then stands for every child)
+      if (!ok) {  // (bounds near the largest f32: no spacing fits; the whole grid then stands for every child)
+        step = std::numeric_limits<float>::max() / 256.0f;
         for (int c = 0; c < 4; ++c)
           if (w.child[c] != 0xFFFFFFFFu) { q.lo[a][c] = 0; q.hi[a][c] = 255; }
-      q.exps |= (uint32_t)(e + 127) << (8 * a);  // the bits of 2^e are (e + 127) << 23
+      }
+      (a == 0 ? q.step_x : a == 1 ? q.step_y : q.step_z) = step;
     }
   }
   return out;

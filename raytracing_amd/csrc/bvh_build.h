@@ -66,18 +66,19 @@ struct WideBvh {
 WideBvh widen_bvh(const std::vector<HostNode>& nodes, uint32_t root_ref);
 
 // The four-child node as the device reads it: one 64-byte line.  The children's boxes are stored as 8-bit offsets
-// on a grid that starts at the node's own minimum corner and has a power-of-two spacing per axis,
-//   lo = fma(q_lo, 2^e, origin)   hi = fma(q_hi, 2^e, origin)      (the same fused operation on the device),
+// on a grid that starts at the node's own minimum corner, with a spacing per axis of 1/255 of the node's extent
+// (the next float up that passes the check below),
+//   lo = fma(q_lo, spacing, origin)   hi = fma(q_hi, spacing, origin)      (one fused operation, rounded once),
 // rounded outwards, so a decoded box always contains the child's true box: walks never miss, they only take the odd
 // extra step.  Four 16-byte loads per step instead of seven; a walk from global memory pays for every load.
-//   q0 = origin.xyz, bits(ex | ey << 8 | ez << 16)  (biased exponents of the grid spacing)
-//   q1 = lo.x[4] lo.y[4] lo.z[4] hi.x[4] as bytes   q2 = hi.y[4] hi.z[4] as bytes, 8 bytes unused   q3 = child refs
+//   q0 = origin.xyz, spacing.x   q1 = lo.x[4] lo.y[4] lo.z[4] hi.x[4] as bytes
+//   q2 = hi.y[4] hi.z[4] as bytes, spacing.y, spacing.z   q3 = child refs
 struct QuantNode {
   float origin[3];
-  uint32_t exps;
+  float step_x;
   uint8_t lo[3][4];
   uint8_t hi[3][4];
-  uint32_t pad[2];
+  float step_y, step_z;
   uint32_t child[4];
 };
 static_assert(sizeof(QuantNode) == 64, "a quantised node is one 64-byte line");

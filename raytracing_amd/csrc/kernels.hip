@@ -420,9 +420,7 @@ __device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float 
   auto quad = [&](int k) { return make_float4(n[k].x, n[k].y, n[k].z, n[k].w); };
   const float4 q0 = quad(0), q1 = quad(1), q2 = quad(2), rq = quad(3);
   uint32_t r0 = __float_as_uint(rq.x), r1 = __float_as_uint(rq.y), r2 = __float_as_uint(rq.z), r3 = __float_as_uint(rq.w);
-  const uint32_t exps = __float_as_uint(q0.w);
-  const float sx = __uint_as_float((exps & 255u) << 23), sy = __uint_as_float(((exps >> 8) & 255u) << 23),
-              sz = __uint_as_float(((exps >> 16) & 255u) << 23);
+  const float sx = q0.w, sy = q2.z, sz = q2.w;  // the grid's spacing per axis
   // Per axis the plane the ray meets first is the lower one when it travels upwards and the upper one otherwise:
   // picked once per node, on the packed bytes of the four children, this saves the per-box min / max of the two.
   const bool up_x = !(w.inv.x < 0.0f), up_y = !(w.inv.y < 0.0f), up_z = !(w.inv.z < 0.0f);
@@ -430,17 +428,19 @@ __device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float 
                  hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
   const uint32_t nx = up_x ? lox : hix, ny = up_y ? loy : hiy, nz = up_z ? loz : hiz;
   const uint32_t fx = up_x ? hix : lox, fy = up_y ? hiy : loy, fz = up_z ? hiz : loz;
-  // The builder checked every plane as P = fma(byte, 2^e, corner), rounded once; the test wants (P - o) / d -+ pad / |d|.
-  // It is taken per plane in one fused multiply-add, byte * (2^e / d) + ((corner - o) / d -+ pad / |d|): the second
+  // The builder checked every plane as P = fma(byte, s, corner), rounded once; the test wants (P - o) / d -+ pad / |d|.
+  // It is taken per plane in one fused multiply-add, byte * (s / d) + ((corner - o) / d -+ pad / |d|): the second
   // term once per node and axis, one padding for the node's four children.
-  //  * The padding is taken with F over the node's whole grid, corner - o to corner - o + 255 * 2^e per axis, which
-  //    holds every child's planes (rounding is monotonic): at least each child's own F.
-  //  * Rounding, with u = 2^-24 and in units of length (times |1/d|): 2^e / d is exact; rel = corner - o rounds by
-  //    u |rel|; the node's term by u (|rel| + pad); the sum by u |P - o|; and the builder's own rounding of P, u |P| <=
-  //    u (|corner| + 255 * 2^e), is not repeated this way.  A plane tested here lies within 2 u |rel| + u |P| + u pad of
-  //    the one the builder checked, besides the u |P - o| any way of testing it has.  3 u of |rel| + |corner| +
-  //    255 * 2^e, taken over the axes and with 5 % to spare for u pad and what it moves the padding's own length by,
-  //    is added to the padding (`slack`): the planes then lie at least as far out as the ones the builder checked.
+  //  * The padding is taken with F over the node's whole grid, corner - o to corner - o + 255 s per axis, which
+  //    holds every child's planes (rounding is monotonic) and is the node's own extent to a few roundings: at least
+  //    each child's own F.
+  //  * Rounding, with u = 2^-24, s the spacing, and in units of length (times |1/d|): s / d rounds by u s, 255 u s
+  //    at the farthest plane; rel = corner - o rounds by u |rel|; the node's term by u (|rel| + pad); the sum by
+  //    u |P - o|; and the builder's own rounding of P, u |P| <= u (|corner| + 255 s), is not repeated this way.  A
+  //    plane tested here lies within 2 u |rel| + 255 u s + u |P| + u pad of the one the builder checked, besides the
+  //    u |P - o| any way of testing it has.  3 u of |rel| + |corner| + 255 s, taken over the axes and with 5 % to
+  //    spare for u pad and what it moves the padding's own length by, is added to the padding (`slack`): the planes
+  //    then lie at least as far out as the ones the builder checked.
   //  * A ray that runs in a plane's direction (d = 0 on an axis) has 1/d infinite: every product and sum on that axis
   //    is then infinite with the sign of "does not constrain" or a NaN, which fminf / fmaxf drop -- no box is missed.
   const V3 rel = xyz(q0) - w.r.o;
