@@ -307,6 +307,21 @@ __device__ __forceinline__ bool slab(V3 bmin, V3 bmax, V3 o, V3 inv, float t_min
   return tn <= tf;
 }
 
+// Path records go past the caches (the non-temporal hint): a record is written once and read once, a phase or a round
+// later, and the pool is far larger than any cache; what the caches hold is then the tree's nodes and the primitive
+// records of a scene in global memory, the textures, and the image's sums.  (+1.4 % on final_scene, +3 % on
+// cornel_box, +4 % on 10 M spheres; the same hint on the primitive records, which rays share, cost 20 %.)
+__device__ __forceinline__ float4 load_quad(const float4* p) {
+  typedef float Quad __attribute__((ext_vector_type(4)));
+  const Quad v = __builtin_nontemporal_load(reinterpret_cast<const Quad*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_quad(float4* p, float4 v) {
+  typedef float Quad __attribute__((ext_vector_type(4)));
+  const Quad q = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(q, reinterpret_cast<Quad*>(p));
+}
+
 struct Work {
   uint32_t nodes, prims;            // steps down the tree and primitive tests, per lane
   uint32_t wave_nodes, wave_prims;  // the same counted once per wave instruction stream (lane 0 only)
@@ -1322,7 +1337,8 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
     uint32_t e = min(first + lane, max(n_stored, 1u) - 1u);
     e = place_of(e);
     if (!MIRT_CHECK(e < cap, A->work, 1, e, cap, n_stored)) return;
-    ahead[0] = cur[e]; ahead[1] = cur[(size_t)cap + e]; ahead[2] = cur[2 * (size_t)cap + e];
+    ahead[0] = load_quad(cur + e); ahead[1] = load_quad(cur + (size_t)cap + e);
+    ahead[2] = load_quad(cur + 2 * (size_t)cap + e);
   };
   if (AHEAD) read_ahead(0u);
   auto from_lane = [](const float4& v, uint32_t byte_address) {
@@ -1400,10 +1416,10 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         // the whole path record moves into the queue, hit included: shading reads its queue front to back
         float4* const out = region_queues + 4 * (size_t)q * cap + pos;
         if (MIRT_CHECK(pos < cap && q < N_QUEUES, A->work, 2, pos, cap, q)) {
-        out[0] = make_float4(w.r.o.x, w.r.o.y, w.r.o.z, w.r.time);
-        out[cap] = make_float4(w.r.d.x, w.r.d.y, w.r.d.z, pixel_bits);
-        out[2 * (size_t)cap] = state;
-        out[3 * (size_t)cap] = make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), __uint_as_float(saved_at));
+        store_quad(out, make_float4(w.r.o.x, w.r.o.y, w.r.o.z, w.r.time));
+        store_quad(out + cap, make_float4(w.r.d.x, w.r.d.y, w.r.d.z, pixel_bits));
+        store_quad(out + 2 * (size_t)cap, state);
+        store_quad(out + 3 * (size_t)cap, make_float4(w.best_t, __uint_as_float(w.best_ref), __uint_as_float(w.best_face), __uint_as_float(saved_at)));
         }
         slot = NO_SLOT;
         w.cur = RC::NONE;
@@ -1419,14 +1435,14 @@ __device__ __noinline__ void walk_rays(const RenderArgs* args, uint32_t lds_arg,
         if (slot == NO_SLOT && entry < total) {
           slot = entry;
           if (entry >= n_stored) camera.start(entry - n_stored, r0, r1, r2);
-          else if (!AHEAD && MIRT_CHECK(place_of(slot) < cap, A->work, 3, slot, cap, n_stored)) { const uint32_t at = place_of(slot); r0 = cur[at]; r1 = cur[(size_t)cap + at]; r2 = cur[2 * (size_t)cap + at]; }
+          else if (!AHEAD && MIRT_CHECK(place_of(slot) < cap, A->work, 3, slot, cap, n_stored)) { const uint32_t at = place_of(slot); r0 = load_quad(cur + at); r1 = load_quad(cur + (size_t)cap + at); r2 = load_quad(cur + 2 * (size_t)cap + at); }
           state = r2;
           pixel_bits = r1.w;
           Ray r;
           r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
           walk_begin(w, r, root, time_slice_base(r.time, n_slices, slice_time0, slice_scale, n_nodes));
           if (!LDS_SCENE && step_budget != 0u && entry < n_stored) {
-            const uint32_t saved_in = __float_as_uint(cur[3 * (size_t)cap + place_of(slot)].x);
+            const uint32_t saved_in = __float_as_uint(load_quad(cur + 3 * (size_t)cap + place_of(slot)).x);
             if (saved_in != 0u) {  // a walk put aside in the last round: on from where it stopped
               const uint4* const sv = saves_in + (size_t)SAVE_QUADS * (saved_in - 1u);
               const uint4 a = sv[0], b = sv[1];
@@ -1525,7 +1541,7 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, state = r0;
     if (live) {
       if (entry >= n_stored) camera.start(entry - n_stored, r0, r1, state);
-      else { r0 = cur[entry]; r1 = cur[(size_t)cap + entry]; state = cur[2 * (size_t)cap + entry]; }
+      else { r0 = load_quad(cur + entry); r1 = load_quad(cur + (size_t)cap + entry); state = load_quad(cur + 2 * (size_t)cap + entry); }
     }
     Ray r;
     r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
@@ -1563,10 +1579,10 @@ __device__ __noinline__ void scan_rays(const RenderArgs* args, uint32_t lds_arg,
     if (live) {
       const uint32_t pos = bq + lanes_below(mq);
       float4* const out = region_queues + 4 * (size_t)q * cap + pos;
-      out[0] = r0;
-      out[cap] = r1;
-      out[2 * (size_t)cap] = state;
-      out[3 * (size_t)cap] = make_float4(best_t, __uint_as_float(best_ref), __uint_as_float(best_face), 0.0f);
+      store_quad(out, r0);
+      store_quad(out + cap, r1);
+      store_quad(out + 2 * (size_t)cap, state);
+      store_quad(out + 3 * (size_t)cap, make_float4(best_t, __uint_as_float(best_ref), __uint_as_float(best_face), 0.0f));
       ++segments;
     }
     if (COUNT) work.cycles[MIRT_PHASE_WRITE] += clock64() - ts;
@@ -1645,7 +1661,8 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
       uint32_t saved_walk = 0;  // 1 + entry of the save area for a ray whose walk was put aside
       if (e < n_q && MIRT_CHECK(from + e < cap, A->work, 5, e, from, n_q)) {
         const float4* const rec = entries + e;
-        const float4 r0 = rec[0], r1 = rec[cap], r2 = rec[2 * (size_t)cap], r3 = rec[3 * (size_t)cap];
+        const float4 r0 = load_quad(rec), r1 = load_quad(rec + cap), r2 = load_quad(rec + 2 * (size_t)cap),
+                     r3 = load_quad(rec + 3 * (size_t)cap);
         Ray r;
         r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
         pixel = __float_as_uint(r1.w);
@@ -1669,6 +1686,8 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
               const uint32_t at = sh.queue_n[to_q] + atomicAdd(&sh.late_n[to_q], 1u);
               float4* const out = region_queues + 4 * (size_t)to_q * cap + at;
               if (MIRT_CHECK(at < cap && to_q < (uint32_t)N_QUEUES, A->work, 6, at, cap, to_q)) {
+              // (plain stores: these few records are read again within this shading pass -- streamed past the
+              // caches like the rest they cost final_scene 3.7 %)
               out[0] = r0; out[cap] = r1; out[2 * (size_t)cap] = r2;
               out[3 * (size_t)cap] = make_float4(t, __uint_as_float(ref), r3.z, r3.w);
               }
@@ -1769,10 +1788,10 @@ __device__ __noinline__ void shade_queues(const RenderArgs* args, uint32_t lds_a
         to = wave_reserve(alive, &sh.n_next);
       }
       if (alive && MIRT_CHECK(to < cap, A->work, 8, to, cap, q)) {
-        next[to] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time);
-        next[cap + to] = make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel));
-        next[2 * (size_t)cap + to] = make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1)));
-        if (budgeted) next[3 * (size_t)cap + to] = make_float4(__uint_as_float(saved_walk), 0.0f, 0.0f, 0.0f);
+        store_quad(next + to, make_float4(nr.o.x, nr.o.y, nr.o.z, nr.time));
+        store_quad(next + cap + to, make_float4(nr.d.x, nr.d.y, nr.d.z, __uint_as_float(pixel)));
+        store_quad(next + 2 * (size_t)cap + to, make_float4(beta.x, beta.y, beta.z, __uint_as_float((sample << 8) | (bounce + 1))));
+        if (budgeted) store_quad(next + 3 * (size_t)cap + to, make_float4(__uint_as_float(saved_walk), 0.0f, 0.0f, 0.0f));
       }
     }
     if (n_media == 0 || pass == 1u) break;
@@ -1793,9 +1812,9 @@ __device__ __noinline__ void start_rays(const RenderArgs* args, bool odd, uint32
   for (uint32_t k = lane_id(); k < n_fresh; k += 64u) {
     const uint64_t g = first_new + k;
     const mirt_ray in = rays[g];
-    cur[k] = make_float4(in.origin[0], in.origin[1], in.origin[2], in.time);
-    cur[cap + k] = make_float4(in.direction[0], in.direction[1], in.direction[2], __uint_as_float((uint32_t)g));
-    cur[2 * cap + k] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    store_quad(cur + k, make_float4(in.origin[0], in.origin[1], in.origin[2], in.time));
+    store_quad(cur + cap + k, make_float4(in.direction[0], in.direction[1], in.direction[2], __uint_as_float((uint32_t)g)));
+    store_quad(cur + 2 * cap + k, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
   }
 }
 
@@ -1832,7 +1851,7 @@ __device__ __noinline__ void report_hits(const RenderArgs* args, uint32_t lds_ar
     const float4* entries = region_queues + 4 * (size_t)q * cap;
     for (uint32_t e = lane_id(); e < n_q; e += 64u) {
       const float4* const rec = entries + e;
-      const float4 r0 = rec[0], r1 = rec[cap], r3 = rec[3 * (size_t)cap];
+      const float4 r0 = load_quad(rec), r1 = load_quad(rec + cap), r3 = load_quad(rec + 3 * (size_t)cap);
       Ray r;
       r.o = xyz(r0); r.time = r0.w; r.d = xyz(r1);
       const uint32_t g = __float_as_uint(r1.w);
