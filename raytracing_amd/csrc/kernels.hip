@@ -113,6 +113,7 @@ struct SceneTables {
   const float4* prims;
   const float4* chains;  // two quads per chain, see ChainHead
   const float4* chain_ops;
+  float min_radius;  // smallest sphere radius of the scene (four-child walk: the box padding depends on it)
 };
 // What shading reads besides the geometry: materials, textures and their tables, the lights to sample.
 struct ShadeTables {
@@ -128,7 +129,7 @@ struct ShadeTables {
   uint32_t lights_mode, n_lights, n_light_groups;
 };
 // Both from a scene description in any address space (kernel argument or constant memory).
-#define MIRT_GLOBAL_TABLES(sc) SceneTables{(sc).nodes, (sc).prims, (sc).chains, (sc).chain_ops}
+#define MIRT_GLOBAL_TABLES(sc) SceneTables{(sc).nodes, (sc).prims, (sc).chains, (sc).chain_ops, (sc).min_radius}
 #define MIRT_SHADE_TABLES(sc)                                                                                   \
   ShadeTables{(sc).materials, (sc).textures, (sc).perlin_vec, (sc).perlin_perm, 0u, (sc).images, (sc).image_data, \
               (sc).lights,    (sc).light_groups, (sc).lights_mode, (sc).n_lights, (sc).n_light_groups}
@@ -465,9 +466,15 @@ __device__ __forceinline__ void wide_step(Walk& w, const SceneTables& tb, float 
   const float slack = BOX_DECODE_SLACK * __builtin_fmaf(255.0f, fmaxf(fmaxf(sx, sy), sz),
                                                        fmaxf(fmaxf(fabsf(rel.x), fabsf(rel.y)), fabsf(rel.z)) +
                                                            fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fabsf(q0.z)));
-  // (v_sqrt_f32: one unit in the last place, part of the constant's margin.  The sum of the three instead of the
-  // root was 8 % more tree steps and a third more primitive tests at 10 M spheres.)
-  const float pad = __builtin_fmaf(BOX_GROW_ANY, __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx))), slack);
+  // How far off a ball of radius >= r the f32 sphere test may still report a hit, F away: sqrt(r^2 + A F^2 + B F r) - r
+  // (scene_device.h), written x / (sqrt(r^2 + x) + r) so that nothing cancels.  v_sqrt_f32 and v_rcp_f32 are good
+  // to a unit in the last place, part of the 5 % margin.  (The sum of the three farthest coordinates instead of
+  // their length was 8 % more tree steps and a third more primitive tests at 10 M spheres.)
+  const float reach = __builtin_amdgcn_sqrtf(__builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx)));
+  const float r_min = tb.min_radius;
+  const float x = reach * __builtin_fmaf(reach, HALO_QUADRATIC, HALO_LINEAR * r_min);
+  const float halo = x * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(__builtin_fmaf(r_min, r_min, x)) + r_min);
+  const float pad = __builtin_fmaf(HALO_MARGIN, halo, __builtin_fmaf(BOX_GROW_FAR_LINEAR, reach, slack));
   const float ex = pad * fabsf(w.inv.x), ey = pad * fabsf(w.inv.y), ez = pad * fabsf(w.inv.z);
   const V3 step = v3(sx * w.inv.x, sy * w.inv.y, sz * w.inv.z);
   const V3 from = v3(__builtin_fmaf(rel.x, w.inv.x, -ex), __builtin_fmaf(rel.y, w.inv.y, -ey), __builtin_fmaf(rel.z, w.inv.z, -ez));
@@ -1168,7 +1175,7 @@ struct RenderLds {
   }
   // the tables the walk and the shading read the scene's geometry from
   __device__ __forceinline__ SceneTables tables(ConstArgs A) const {
-    if (LDS_SCENE) return SceneTables{nodes, prims, chains, ops};
+    if (LDS_SCENE) return SceneTables{nodes, prims, chains, ops, 0.0f};
     return MIRT_GLOBAL_TABLES(A->sc);
   }
 };

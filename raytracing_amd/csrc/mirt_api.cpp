@@ -835,6 +835,15 @@ static int upload_one(mirt_context* ctx, const mirt_scene_desc* desc, mirt_scene
   v.slice_scale = n_slices > 1 ? (float)n_slices / (d.time1 - d.time0) : 0.0f;
   v.wide = wide ? 1u : 0u;
   v.keep_out = keep_out;
+  {  // the four-child walk's box padding takes the scene's smallest sphere radius (scene_device.h)
+    float r_min = 1e15f;
+    for (size_t j = 0; j < build.size(); ++j) {
+      const uint32_t g = build[j].id;
+      if (g >= first_of_tag[TAG_RECT]) continue;
+      r_min = std::min(r_min, std::fabs(src[PRIM_QUADS * (size_t)g].w));
+    }
+    v.min_radius = std::max(r_min, 0.0f);
+  }
   v.bvh_height = s.bvh_height;
   v.n_chains = d.n_chains;
   v.prims = s.prims.as<float4>();

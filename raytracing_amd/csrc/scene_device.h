@@ -74,15 +74,23 @@ constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 //    6 u |o|; the box test's own subtractions, reciprocals and fused multiply-adds are off by 4 u L.
 //    BOX_GROW_LINEAR = 64 u covers the parts in L (spheres 33 u + 4 u, rects 8 u + 4 u), the builder's own padding
 //    of 170 u |box| (Bounds::pad) the rest.
-// Scenes walked from global memory use the first, BOX_GROW_ANY * F, F the Euclidean length of the box's farthest
-// |coordinates| relative to the ray origin (F >= M: the box holds the ball): BOX_GROW_ANY = 1.06e-3 leaves 5 % --
-// a hundred times what the box test's own rounding (4 u F), its one-instruction square root and the decoded box's
-// rounding (outwards, by the builder) take.  For rects and box sides 1.06e-3 F is far more than the 64 u L they
-// need.  (At a thousand units from a sphere of radius 0.2 the second bound would be 2.6 units: there the f32 test no
-// longer resolves r^2 in |os|^2 - r^2, and the first bound, 1 unit, is what it may really report as hits.)
+// Scenes walked from global memory use |P - centre| - r <= sqrt(r^2 + A + B r) - r itself, with F for M -- the
+// Euclidean length of the farthest |coordinates| of the node's boxes relative to the ray origin (F >= M: the box
+// holds the ball) -- and the smallest sphere radius of the scene for r (the expression falls as r grows, since
+// B^2 < 4 A; a scene without spheres has r huge and the term all but vanishes):
+//   pad = HALO_MARGIN * (sqrt(r^2 + x) - r) + BOX_GROW_FAR_LINEAR * F,   x = F (HALO_QUADRATIC F + HALO_LINEAR r),
+// HALO_QUADRATIC = 17.1 u, HALO_LINEAR = 36 u, 5 % on top as the LDS rule's factor stands for, and a linear part
+// for the rounding of origin - centre (u F), for rects and box sides (64 u L) and for the box test's own arithmetic
+// (4 u F and the decoded planes' rounding, which has a term of its own: BOX_DECODE_SLACK).  For r -> 0 this is the
+// "any radius" bound, 1.06e-3 F; a thousand units from a sphere of radius 0.2 it is 0.83 F / 1000 + ..., four
+// hundred units away 0.25 where the radius-free bound has 0.40: the f32 test no longer resolves r^2 in |os|^2 - r^2
+// there, and these are the hits it may really report.
 constexpr float BOX_GROW_SPHERE = 3.814697265625e-06f;  // 2^-18
 constexpr float BOX_GROW_LINEAR = 3.814697265625e-06f;  // 2^-18
-constexpr float BOX_GROW_ANY = 1.06e-3f;
+constexpr float HALO_QUADRATIC = 1.0192394e-06f;         // 17.1 * 2^-24
+constexpr float HALO_LINEAR = 2.1457672e-06f;            // 36 * 2^-24
+constexpr float HALO_MARGIN = 1.05f;
+constexpr float BOX_GROW_FAR_LINEAR = 4.4703484e-06f;    // 75 * 2^-24
 // Four-child nodes are tested relative to the ray origin, a plane in one fused multiply-add (wide_step): what that
 // adds to the rounding of a plane, per unit of |corner - origin| + |corner| + 255 * grid spacing: 3 u = 3 * 2^-24 and
 // 5 % (derivation at wide_step).
@@ -152,6 +160,7 @@ struct DeviceScene {
   float slice_time0, slice_scale;
   uint32_t wide;  // nodes are four-child WideNodes (the scene is walked from global memory)
   uint32_t n_perlins;  // noise tables (256 vectors and 3 x 256 permutation entries each)
+  float min_radius;   // smallest radius of a sphere in the tree (at most 1e15; that much for a scene without spheres)
   uint32_t keep_out;  // never staged in LDS, whatever its size (MIRT_NO_LDS at upload: a small scene through the large scenes' code)
 
   const float4* prims;  // primitive records, layout above
