@@ -70,11 +70,14 @@ def test_random_sphere_fields_match_the_exhaustive_scan(scale, n, seed, builder,
     assert np.array_equal(t.view(np.uint32), want_t.view(np.uint32))
 
 
-@pytest.mark.parametrize("scale,seed,builder,far,n", [(1.0, 21, "host", 30.0, 400), (1e3, 22, "host", 300.0, 400),
-                                                      (1e-2, 23, "device", 30.0, 400), (1.0, 24, "host", 3000.0, 400),
-                                                      (1.0, 25, "host", 3000.0, 4500), (10.0, 26, "device", 300.0, 4500),
-                                                      (1.0, 27, "host", 30000.0, 4500), (0.1, 28, "device", 30000.0, 4500)])
-def test_rays_that_graze_spheres_match_the_exhaustive_scan(scale, seed, builder, far, n, monkeypatch):
+@pytest.mark.parametrize("scale,seed,builder,far,n,radius", [
+    (1.0, 21, "host", 30.0, 400, None), (1e3, 22, "host", 300.0, 400, None), (1e-2, 23, "device", 30.0, 400, None),
+    (1.0, 24, "host", 3000.0, 400, None), (1.0, 25, "host", 3000.0, 4500, None), (10.0, 26, "device", 300.0, 4500, None),
+    (1.0, 27, "host", 30000.0, 4500, None), (0.1, 28, "device", 30000.0, 4500, None),
+    # every sphere of one radius: the padding of a four-child walk depends on the scene's smallest radius, and only a
+    # scene without small spheres gets less of it than the radius-free bound gives
+    (1.0, 29, "host", 3000.0, 4500, 0.2), (1.0, 30, "device", 300.0, 4500, 0.05), (10.0, 31, "device", 3000.0, 4500, 0.3)])
+def test_rays_that_graze_spheres_match_the_exhaustive_scan(scale, seed, builder, far, n, radius, monkeypatch):
     """Rays aimed at the rim of a sphere from up to thousands of radii away, passing it within a few times the
     distance at which the f32 discriminant (objects.rs:46-50) can no longer tell a hit from a miss: the scan reports
     hits for some rays that miss the exact sphere, and the boxes of the tree have to let every one of them through.
@@ -85,6 +88,8 @@ def test_rays_that_graze_spheres_match_the_exhaustive_scan(scale, seed, builder,
     # walked from global memory)
     centers = (rng.uniform(-10, 10, (n, 3)) * scale).astype(F)
     radii = (np.exp(rng.normal(-2.0 if n < 1000 else -3.0, 1.2, n)) * scale).astype(F)   # 0.004 .. 5 times the scale
+    if radius is not None:
+        radii = np.full(n, radius * scale, F)
     m = 60000
     on = rng.integers(0, n, m)
     c, r = centers[on].astype(np.float64), radii[on].astype(np.float64)[:, None]
